@@ -1,0 +1,128 @@
+/*
+ * shapemol_hip.h -- C ABI of the MI355X (gfx950) implementation of ShapeMol's denoising hot path.
+ *
+ * The reference has no FFI of its own (it is pure Python on third-party torch ops), so the
+ * boundary is its Python call surface; each entry point below names the reference call it
+ * replaces (paths relative to the reference repository root):
+ *
+ *   shapemol_create / _destroy     ScorePosNet3D.__init__ + load_state_dict
+ *                                  models/molopt_score_model.py:171-283, scripts/sample_diffusion.py:211-215
+ *   shapemol_score                 ScorePosNet3D.forward        models/molopt_score_model.py:286-320
+ *                                  (-> UniTransformerO2TwoUpdateGeneral.forward, models/uni_transformer.py:483-540)
+ *   shapemol_sample                ScorePosNet3D.sample_diffusion  models/molopt_score_model.py:533-697
+ *   shapemol_log_sample_categorical  log_sample_categorical     models/molopt_score_model.py:98-104
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every `d_` pointer is DEVICE memory on the context's device,
+ *     caller-owned, float32 / int64 exactly as the reference's tensors (row-major, contiguous);
+ *     outputs are caller-allocated.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - no hidden host synchronisation in _score/_sample/_log_sample_categorical: work is enqueued on
+ *     `stream` and the call returns; the caller synchronises.
+ *   - return 0 on success, non-zero on error; shapemol_last_error() returns the message of the last
+ *     failing call on this thread.
+ *   - one context per device; a context is not thread-safe.
+ */
+#ifndef SHAPEMOL_HIP_H
+#define SHAPEMOL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHAPEMOL_ABI_VERSION 1
+
+typedef struct shapemol_ctx shapemol_ctx;
+
+/* `model` section of the training YAML (config/training/*.yml:21-74), reduced to what the path uses. */
+typedef struct shapemol_config {
+    int32_t hidden_dim;        /* 128 */
+    int32_t n_heads;           /* 16  (hidden_dim / n_heads must be 8) */
+    int32_t num_layers;        /* 8   */
+    int32_t knn;               /* 8   (1..32) */
+    int32_t num_r_gaussian;    /* 20  (the reference hard-codes 20 centres) */
+    int32_t shape_dim;         /* 32  point-cloud latent vectors per molecule, each in R^3 */
+    int32_t shape_latent_dim;  /* 32  */
+    int32_t time_emb_dim;      /* 8   */
+    int32_t num_classes;       /* 15  */
+    int32_t num_timesteps;     /* 1000 */
+} shapemol_config;
+
+int shapemol_abi_version(void);
+const char *shapemol_last_error(void);
+
+/* Number of float32 values shapemol_create expects in `weights` for this config: every float entry
+ * of the reference state dict, in registration order, densely concatenated (the int64
+ * `num_batches_tracked` counters are skipped).  shapemol_amd.pack_state_dict builds it. */
+size_t shapemol_weight_count(const shapemol_config *cfg);
+
+/* weights: HOST pointer to shapemol_weight_count() floats.  device: HIP device ordinal. */
+int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_weights,
+                    int device, shapemol_ctx **out);
+void shapemol_destroy(shapemol_ctx *ctx);
+
+/* Pre-size the workspace (otherwise it grows on demand, which allocates). */
+int shapemol_reserve(shapemol_ctx *ctx, int64_t max_atoms, int64_t max_mols);
+
+/* One score evaluation.
+ *   d_pos   (N,3) f32   ligand_pos_perturbed      d_v     (N,) i64  ligand_v_perturbed
+ *   d_batch (N,) i64 sorted molecule id per atom  d_shape (B,shape_dim,3) f32  ligand_shape
+ *   d_t     (B,) i64    time_step
+ *   out_pos (N,3) f32   pred_ligand_pos   out_h (N,H) f32 pred_ligand_h (may be NULL)
+ *   out_v   (N,C) f32   pred_ligand_v */
+int shapemol_score(shapemol_ctx *ctx, const float *d_pos, const int64_t *d_v, const int64_t *d_batch,
+                   int64_t n_atoms, int64_t n_mols, const float *d_shape, const int64_t *d_t,
+                   float *out_pos, float *out_h, float *out_v, void *stream);
+
+/* Trajectory buffers of shapemol_sample; any pointer may be NULL (that trajectory is not kept).
+ * All are DEVICE buffers with a leading num_steps dimension. */
+typedef struct shapemol_traj {
+    float   *pos_traj;       /* (S,N,3)  x_{t-1} after each step          (pos_traj)       */
+    int64_t *v_traj;         /* (S,N)    v_{t-1} after each step          (v_traj)         */
+    float   *v0_traj;        /* (S,N,C)  log_softmax of predicted logits  (v0_traj)        */
+    float   *vt_traj;        /* (S,N,C)  log posterior q(v_{t-1}|v_t,v0)  (vt_traj)        */
+    float   *pos_cond_traj;  /* (S,N,3)  raw network x0 prediction        (pos_cond_traj)  */
+    float   *v_cond_traj;    /* (S,N,C)  raw network logits               (v_cond_traj)    */
+} shapemol_traj;
+
+/* Reverse chain t = T-1 ... T-num_steps (center_pos_mode 'none', no guidance).
+ *   d_init_pos (N,3) f32, d_init_v (N,) i64, d_batch, d_shape as in shapemol_score.
+ *   Noise: if d_eps != NULL and d_u != NULL they are host-chosen draws, eps (S,N,3) ~ N(0,1) and
+ *   u (S,N,C) ~ U[0,1), consumed per step in the reference's order (randn_like then rand_like,
+ *   models/molopt_score_model.py:662,99).  Otherwise noise is generated on the device
+ *   (Philox4x32-10 keyed by `seed`, Box-Muller).
+ *   out_pos (N,3) f32, out_v (N,) i64: final state.  use_graph != 0 replays one captured
+ *   hipGraph per step. */
+int shapemol_sample(shapemol_ctx *ctx, const float *d_init_pos, const int64_t *d_init_v,
+                    const int64_t *d_batch, int64_t n_atoms, int64_t n_mols, const float *d_shape,
+                    int32_t num_steps, const float *d_eps, const float *d_u, uint64_t seed,
+                    const shapemol_traj *traj, float *out_pos, int64_t *out_v,
+                    int32_t use_graph, void *stream);
+
+/* argmax_c( logits[n,c] - log(-log(u[n,c] + 1e-30) + 1e-30) ); d_u NULL -> device Philox(seed). */
+int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, const float *d_u,
+                                    int64_t n_rows, int32_t n_classes, uint64_t seed,
+                                    int64_t *out_index, void *stream);
+
+/* ---- diagnostics (used by the parity tests and the bench; not needed by a caller) ---- */
+/* options: "stop_layer" (run only the first v layers of the next _score; -1 = all),
+ *          "edge_waves" / "node_waves" (waves per workgroup, tuning). */
+int shapemol_set_option(shapemol_ctx *ctx, const char *name, int64_t value);
+/* Copy an internal device buffer of the last _score to HOST memory (synchronises the device).
+ * names: "nbr" (N,KP) i32, "ew" (N,KP) f32, "h" (N,H), "x" (N,3), "pre" (N,4H), "q" (N,H),
+ *        "att" (N,H), "o3" (N,heads*3), "bnstat" (L,2,heads) f64, "dims" (8,) i64.
+ * Returns the number of bytes written, or -1. */
+int64_t shapemol_debug_read(shapemol_ctx *ctx, const char *name, void *host_dst, size_t max_bytes);
+/* Per-kernel launch-time accounting with HIP events on the launch stream (bench only).
+ * shapemol_profile_begin() arms it for the following _score/_sample calls (forces eager launches);
+ * shapemol_profile_end() synchronises and writes, for each of up to `cap` kernel classes,
+ * name / total milliseconds / launch count.  Returns the number of classes. */
+int shapemol_profile_begin(shapemol_ctx *ctx);
+int shapemol_profile_end(shapemol_ctx *ctx, char (*names)[32], double *total_ms, int64_t *launches, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHAPEMOL_HIP_H */

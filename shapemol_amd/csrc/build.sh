@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build libshapemol_hip.so for gfx950 (MI355X).  Usage: build.sh [--report]
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libshapemol_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-comment"
+if [[ "${1:-}" == "--report" ]]; then
+  hipcc $FLAGS -o $OUT shapemol_hip.hip -Rpass-analysis=kernel-resource-usage 2>&1 \
+   | grep -E "Function Name|VGPRs:|AGPRs|Scratch|Occupancy|LDS Size|VGPRs Spill" | paste - - - - - - - \
+   | sed -E 's/.*Function Name: ([^ ]+).*VGPRs: ([0-9]+).*AGPRs: ([0-9]+).*ScratchSize \[bytes\/lane\]: ([0-9]+).*Occupancy \[waves\/SIMD\]: ([0-9]+).*VGPRs Spill: ([0-9]+).*LDS Size \[bytes\/block\]: ([0-9]+).*/\1 vgpr=\2 agpr=\3 scratch=\4 occ=\5 spill=\6 lds=\7/' \
+   | c++filt | cut -c1-160
+else
+  hipcc $FLAGS -o $OUT shapemol_hip.hip
+fi

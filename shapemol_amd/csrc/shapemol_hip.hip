@@ -1,0 +1,675 @@
+// libshapemol_hip.so -- C ABI (include/shapemol_hip.h) over the gfx950 kernels.
+// Host side: weight repacking into MFMA-friendly images, workspace, launch sequences for one
+// score evaluation (ScorePosNet3D.forward) and for the reverse chain (sample_diffusion), hipGraph
+// capture of one chain step, per-kernel event timing.
+#include "../../include/shapemol_hip.h"
+#include "sm_device.h"
+#include "sm_edge.h"
+#include "sm_node.h"
+#include "sm_misc.h"
+
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string &m) { g_err = m; return 1; }
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+constexpr int kEdgeThreadsDefault = 512;
+constexpr int kNodeThreadsDefault = 512;
+
+// ---- host view of the packed weight array (order documented in shapemol_amd/packing.py) ----
+struct Lin { const float *w = nullptr, *b = nullptr; int out = 0, in = 0; };
+struct Mlp { Lin l1; const float *g = nullptr, *be = nullptr; Lin l2; };
+struct Cursor {
+    const float *p; size_t left;
+    bool ok = true;
+    const float *take(size_t n) {
+        if (n > left) { ok = false; return p; }
+        const float *r = p; p += n; left -= n; return r;
+    }
+    Lin lin(int out, int in, bool bias = true) {
+        Lin l; l.out = out; l.in = in; l.w = take((size_t)out * in); l.b = bias ? take(out) : nullptr; return l;
+    }
+    Mlp mlp(int in, int hid, int out) {
+        Mlp m; m.l1 = lin(hid, in); m.g = take(hid); m.be = take(hid); m.l2 = lin(out, hid); return m;
+    }
+};
+struct HostLayer { Mlp hk, hv, hq, no, xk, xv, xq; const float *vn_f, *bn_g, *bn_b, *vn_d; };
+struct HostModel {
+    const float *tab[7];
+    Lin te1, te2, emb;
+    Mlp ew;
+    std::vector<HostLayer> layer;
+    Mlp inv;
+    Lin v1, v2;
+};
+
+size_t weight_count(const shapemol_config &c) {
+    const size_t H = c.hidden_dim, G = c.num_r_gaussian, S = c.shape_dim, SL = c.shape_latent_dim,
+                 D = c.time_emb_dim, C = c.num_classes, T = c.num_timesteps, hd = c.n_heads;
+    const size_t kv = G + 2 * H + SL, cin = 1 + hd + S;
+    auto mlp = [](size_t in, size_t hid, size_t out) { return hid * in + hid + 2 * hid + out * hid + out; };
+    size_t n = 7 * T;
+    n += 2 * D * D + 2 * D + D * 2 * D + D;
+    n += H * (C + D) + H;
+    n += mlp(G, H, 1);
+    const size_t per_layer = 2 * mlp(kv, H, H) + mlp(H, H, H) + mlp(2 * H, H, H) + mlp(kv, H, H) +
+                             mlp(kv, H, hd) + mlp(H, H, H) + 2 * hd * cin + 2 * hd;
+    n += (size_t)c.num_layers * per_layer;
+    n += mlp(S, S, SL);
+    n += H * H + H + C * H + C;
+    return n;
+}
+
+bool parse_weights(const shapemol_config &c, const float *w, size_t n, HostModel &m) {
+    const int H = c.hidden_dim, G = c.num_r_gaussian, S = c.shape_dim, SL = c.shape_latent_dim,
+              D = c.time_emb_dim, C = c.num_classes, T = c.num_timesteps, hd = c.n_heads;
+    const int kv = G + 2 * H + SL, cin = 1 + hd + S;
+    Cursor cu{w, n};
+    for (int i = 0; i < 7; ++i) m.tab[i] = cu.take(T);
+    m.te1 = cu.lin(2 * D, D);
+    m.te2 = cu.lin(D, 2 * D);
+    m.emb = cu.lin(H, C + D);
+    m.ew = cu.mlp(G, H, 1);
+    m.layer.resize(c.num_layers);
+    for (auto &L : m.layer) {
+        L.hk = cu.mlp(kv, H, H); L.hv = cu.mlp(kv, H, H); L.hq = cu.mlp(H, H, H); L.no = cu.mlp(2 * H, H, H);
+        L.xk = cu.mlp(kv, H, H); L.xv = cu.mlp(kv, H, hd); L.xq = cu.mlp(H, H, H);
+        L.vn_f = cu.take((size_t)hd * cin); L.bn_g = cu.take(hd); L.bn_b = cu.take(hd); L.vn_d = cu.take((size_t)hd * cin);
+    }
+    m.inv = cu.mlp(S, S, SL);
+    m.v1 = cu.lin(H, H);
+    m.v2 = cu.lin(C, H);
+    return cu.ok && cu.left == 0;
+}
+
+// ---- device image builder --------------------------------------------------------------------
+struct Image {
+    std::vector<float> d;
+    size_t alloc(size_t n) {
+        const size_t off = (d.size() + 63) & ~size_t(63);
+        d.resize(off + n, 0.f);
+        return off;
+    }
+    size_t put(const float *src, size_t n) { const size_t o = alloc(n); std::memcpy(&d[o], src, n * sizeof(float)); return o; }
+};
+
+struct DevMlp { size_t w1, b1, g, be, w2, b2; };
+struct DevLayer {
+    size_t pre_x2h, pre_h2x;          // [4H][H] concatenated first-layer node blocks (k_i, k_j, v_i, v_j)
+    size_t sk_x2h, sv_x2h, sk_h2x, sv_h2x;   // [H][SL] shape columns of the first layers
+    size_t bk_x2h, bv_x2h, bk_h2x, bv_h2x;   // first-layer biases [H]
+    DevMlp q_x2h, q_h2x, no;
+    size_t blob_x2h, blob_h2x;
+    size_t vn_f, vn_d;                // original [heads][cin]
+    size_t wf_x, wd_x, wf_o, wd_o, bn_g, bn_b;
+};
+struct DevModel {
+    size_t tab[7];
+    size_t te1w, te1b, te2w, te2b, embw, embb;
+    DevMlp ew, inv;
+    size_t v1w, v1b, v2w, v2b;   // v2 padded to 16 rows
+    std::vector<DevLayer> layer;
+};
+
+int head_of_row(int m, int nt) {     // value row 4g + r of the h2x edge kernel -> head index, -1 = padding
+    const int g = m >> 2, r = m & 3;
+    if (r >= nt / 2) return -1;
+    return 2 * ((nt / 2) * (g & 1) + r) + (g >> 1);
+}
+
+// pack one edge MLP into the EdgeBlob image (see sm_edge.h)
+void pack_edge_mlp(const Mlp &m, int H, int kv_in, bool perm_heads, float *wr, float *w2, float *gam, float *bet, float *b2) {
+    const int NT = H / 16;
+    const int nt2 = perm_heads ? 1 : NT;
+    for (int t = 0; t < NT; ++t)
+        for (int s = 0; s < 5; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                wr[(t * 5 + s) * 64 + lane] = m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * s + (lane >> 4)];
+    for (int t2 = 0; t2 < nt2; ++t2)
+        for (int t = 0; t < NT; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    int row = 16 * t2 + (lane & 15);
+                    if (perm_heads) row = head_of_row(lane & 15, NT);
+                    const int col = 16 * t + 4 * (lane >> 4) + r;
+                    w2[((t2 * NT + t) * 64 + lane) * 4 + r] = row < 0 ? 0.f : m.l2.w[(size_t)row * H + col];
+                }
+    std::memcpy(gam, m.g, H * sizeof(float));
+    std::memcpy(bet, m.be, H * sizeof(float));
+    for (int i = 0; i < nt2 * 16; ++i) {
+        int row = i;
+        if (perm_heads) row = head_of_row(i, NT);
+        b2[i] = row < 0 ? 0.f : m.l2.b[row];
+    }
+}
+
+template <int H>
+void build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D) {
+    const int G = c.num_r_gaussian, SL = c.shape_latent_dim, S = c.shape_dim, hd = c.n_heads;
+    const int kv = G + 2 * H + SL, cin = 1 + hd + S, NT = H / 16;
+    auto put_pre = [&](const Mlp &k, const Mlp &v) {
+        const size_t o = im.alloc((size_t)4 * H * H);
+        const Mlp *src[4] = {&k, &k, &v, &v};
+        for (int blk = 0; blk < 4; ++blk)
+            for (int f = 0; f < H; ++f)
+                std::memcpy(&im.d[o + ((size_t)blk * H + f) * H], src[blk]->l1.w + (size_t)f * kv + G + (blk & 1) * H, H * sizeof(float));
+        return o;
+    };
+    auto put_scols = [&](const Mlp &m) {
+        const size_t o = im.alloc((size_t)H * SL);
+        for (int f = 0; f < H; ++f) std::memcpy(&im.d[o + (size_t)f * SL], m.l1.w + (size_t)f * kv + G + 2 * H, SL * sizeof(float));
+        return o;
+    };
+    auto put_mlp = [&](const Mlp &m) {
+        DevMlp d;
+        d.w1 = im.put(m.l1.w, (size_t)m.l1.out * m.l1.in); d.b1 = im.put(m.l1.b, m.l1.out);
+        d.g = im.put(m.g, m.l1.out); d.be = im.put(m.be, m.l1.out);
+        d.w2 = im.put(m.l2.w, (size_t)m.l2.out * m.l2.in); d.b2 = im.put(m.l2.b, m.l2.out);
+        return d;
+    };
+    D.pre_x2h = put_pre(L.hk, L.hv); D.pre_h2x = put_pre(L.xk, L.xv);
+    D.sk_x2h = put_scols(L.hk); D.sv_x2h = put_scols(L.hv); D.sk_h2x = put_scols(L.xk); D.sv_h2x = put_scols(L.xv);
+    D.bk_x2h = im.put(L.hk.l1.b, H); D.bv_x2h = im.put(L.hv.l1.b, H);
+    D.bk_h2x = im.put(L.xk.l1.b, H); D.bv_h2x = im.put(L.xv.l1.b, H);
+    D.q_x2h = put_mlp(L.hq); D.q_h2x = put_mlp(L.xq); D.no = put_mlp(L.no);
+    {
+        using B = EdgeBlob<H, false>;
+        const size_t o = im.alloc(B::TOTAL); D.blob_x2h = o; float *b = &im.d[o];
+        pack_edge_mlp(L.hk, H, kv, false, b + B::K_WR, b + B::K_W2, b + B::K_G, b + B::K_B, b + B::K_B2);
+        pack_edge_mlp(L.hv, H, kv, false, b + B::V_WR, b + B::V_W2, b + B::V_G, b + B::V_B, b + B::V_B2);
+    }
+    {
+        using B = EdgeBlob<H, true>;
+        const size_t o = im.alloc(B::TOTAL); D.blob_h2x = o; float *b = &im.d[o];
+        pack_edge_mlp(L.xk, H, kv, false, b + B::K_WR, b + B::K_W2, b + B::K_G, b + B::K_B, b + B::K_B2);
+        pack_edge_mlp(L.xv, H, kv, true, b + B::V_WR, b + B::V_W2, b + B::V_G, b + B::V_B, b + B::V_B2);
+    }
+    D.vn_f = im.put(L.vn_f, (size_t)hd * cin); D.vn_d = im.put(L.vn_d, (size_t)hd * cin);
+    D.bn_g = im.put(L.bn_g, hd); D.bn_b = im.put(L.bn_b, hd);
+    D.wf_x = im.alloc(hd); D.wd_x = im.alloc(hd); D.wf_o = im.alloc((size_t)hd * 16); D.wd_o = im.alloc((size_t)hd * 16);
+    for (int ch = 0; ch < hd; ++ch) {
+        im.d[D.wf_x + ch] = L.vn_f[(size_t)ch * cin];
+        im.d[D.wd_x + ch] = L.vn_d[(size_t)ch * cin];
+        for (int m = 0; m < 16; ++m) {
+            const int hh = head_of_row(m, NT);
+            im.d[D.wf_o + ch * 16 + m] = hh < 0 ? 0.f : L.vn_f[(size_t)ch * cin + 1 + hh];
+            im.d[D.wd_o + ch * 16 + m] = hh < 0 ? 0.f : L.vn_d[(size_t)ch * cin + 1 + hh];
+        }
+    }
+}
+
+struct ProfRec { const char *name; hipEvent_t e0, e1; };
+
+}  // namespace
+
+struct shapemol_ctx {
+    shapemol_config cfg{};
+    int device = 0;
+    int KP = 8;
+    float *d_img = nullptr;
+    DevModel dm;
+    // workspace
+    int64_t capN = 0, capB = 0;
+    std::vector<void *> allocs;
+    int *mol_of = nullptr, *mol_off = nullptr, *t_mol = nullptr, *nbr = nullptr, *steps = nullptr;
+    float *temb = nullptr, *inv = nullptr, *add = nullptr, *ps = nullptr, *ew = nullptr;
+    float *h_a = nullptr, *h_b = nullptr, *pre = nullptr, *q = nullptr, *att = nullptr, *o3 = nullptr, *pd = nullptr;
+    float *x_a = nullptr, *x_b = nullptr, *x_state = nullptr, *pred_pos = nullptr, *pred_v = nullptr;
+    int64_t *v_state = nullptr;
+    double *bn_acc = nullptr;
+    // last evaluation (debug_read)
+    int64_t lastN = 0, lastB = 0;
+    const float *last_h = nullptr, *last_x = nullptr;
+    // options
+    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, node_threads = kNodeThreadsDefault;
+    int num_cu = 256;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    // graph cache
+    hipGraphExec_t gexec = nullptr;
+    struct GraphKey { int64_t N, B; const void *eps, *u, *tp[6]; uint64_t seed; int steps; bool operator==(const GraphKey &o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; } } gkey{};
+    const float *P(size_t off) const { return d_img + off; }
+};
+
+namespace {
+
+template <typename F>
+int launch(shapemol_ctx *c, const char *name, hipStream_t s, F &&f) {
+    if (c->prof_on) {
+        ProfRec r{name, nullptr, nullptr};
+        HIPCHK(hipEventCreate(&r.e0)); HIPCHK(hipEventCreate(&r.e1));
+        HIPCHK(hipEventRecord(r.e0, s));
+        f();
+        HIPCHK(hipEventRecord(r.e1, s));
+        c->prof.push_back(r);
+    } else {
+        f();
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+#define LAUNCH(name, ...) do { if (launch(c, name, s, [&]() { __VA_ARGS__; })) return 1; } while (0)
+
+int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
+    if (N <= c->capN && B <= c->capB) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    for (void *p : c->allocs) hipFree(p);
+    c->allocs.clear();
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    const int64_t capN = std::max<int64_t>(N, c->capN), capB = std::max<int64_t>(B, c->capB);
+    const shapemol_config &g = c->cfg;
+    const int H = g.hidden_dim, L = g.num_layers, hd = g.n_heads;
+    auto A = [&](auto **p, size_t n) -> int {
+        void *q = nullptr;
+        HIPCHK(hipMalloc(&q, n * sizeof(**p) + 256));
+        HIPCHK(hipMemset(q, 0, n * sizeof(**p) + 256));
+        c->allocs.push_back(q);
+        *p = reinterpret_cast<std::remove_reference_t<decltype(*p)>>(q);
+        return 0;
+    };
+    if (A(&c->mol_of, capN) || A(&c->mol_off, capB + 1) || A(&c->t_mol, capB) || A(&c->nbr, capN * c->KP) ||
+        A(&c->steps, 4) || A(&c->temb, capB * g.time_emb_dim) || A(&c->inv, capB * g.shape_latent_dim) ||
+        A(&c->add, (size_t)L * 2 * capB * 4 * H) || A(&c->ps, (size_t)L * capB * 2 * hd * 3) || A(&c->ew, capN * c->KP) ||
+        A(&c->h_a, capN * H) || A(&c->h_b, capN * H) || A(&c->pre, capN * 4 * H) || A(&c->q, capN * H) ||
+        A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
+        A(&c->x_b, capN * 3) || A(&c->x_state, capN * 3) || A(&c->pred_pos, capN * 3) ||
+        A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->bn_acc, (size_t)L * 2 * hd))
+        return 1;
+    c->capN = capN; c->capB = capB;
+    return 0;
+}
+
+template <int H>
+int set_edge_attr(int KP) {
+    const int b0 = EdgeBlob<H, false>::TOTAL * 4, b1 = EdgeBlob<H, true>::TOTAL * 4;
+#define SETATTR(K)                                                                                                    \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_attention_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b0)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_attention_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b1));
+    if (KP == 8) { SETATTR(8) } else if (KP == 16) { SETATTR(16) } else { SETATTR(32) }
+#undef SETATTR
+    return 0;
+}
+
+template <int H, bool H2X>
+int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {
+    const int KP = c->KP;
+    const int apj = KP >= 16 ? 1 : 16 / KP;
+    const int njobs = (a.n_atoms + apj - 1) / apj;
+    const int grid = std::max(1, std::min(c->num_cu, njobs));
+    const size_t shm = EdgeBlob<H, H2X>::TOTAL * sizeof(float);
+    const char *nm = H2X ? "edge_h2x" : "edge_x2h";
+    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 8, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    else if (KP == 16) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 16, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    else LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    return 0;
+}
+
+NodeJob mlp_job(const shapemol_ctx *c, const DevMlp &m, const float *in0, const float *in1, int K, int H,
+                int mode, int n_out2, const float *resid, float *out, int ld_out, int n_store) {
+    NodeJob j{};
+    j.in0 = in0; j.in1 = in1; j.w1 = c->P(m.w1); j.b1 = c->P(m.b1); j.ldw1 = K; j.n_out1 = H; j.mode = mode;
+    j.ln_g = c->P(m.g); j.ln_b = c->P(m.be); j.w2 = c->P(m.w2); j.b2 = c->P(m.b2); j.n_out2 = n_out2;
+    j.resid = resid; j.out = out; j.ld_out = ld_out; j.n_store = n_store;
+    return j;
+}
+
+// Step-invariant per-batch quantities (molecule index, invariant shape embedding, shape terms)
+template <int H>
+int run_prep(shapemol_ctx *c, hipStream_t s, const int64_t *d_batch, int64_t N, int64_t B, const float *d_shape) {
+    const shapemol_config &g = c->cfg;
+    const int L = g.num_layers, hd = g.n_heads, SL = g.shape_latent_dim, S = g.shape_dim;
+    LAUNCH("prep", hipLaunchKernelGGL(mol_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_batch, (int)N, (int)B, c->mol_of, c->mol_off));
+    ShapeInvArgs si{d_shape, c->P(c->dm.inv.w1), c->P(c->dm.inv.b1), c->P(c->dm.inv.g), c->P(c->dm.inv.be),
+                    c->P(c->dm.inv.w2), c->P(c->dm.inv.b2), c->inv, S, SL};
+    LAUNCH("prep", hipLaunchKernelGGL(shape_invariant_kernel, dim3(B), dim3(64), 0, s, si));
+    for (int l = 0; l < L; ++l) {
+        const DevLayer &D = c->dm.layer[l];
+        ShapeTermArgs st{c->inv, c->P(D.sk_x2h), c->P(D.bk_x2h), c->P(D.sv_x2h), c->P(D.bv_x2h),
+                         c->add + ((size_t)l * 2 + 0) * c->capB * 4 * H, SL, H, SL};
+        LAUNCH("prep", hipLaunchKernelGGL(shape_term_kernel, dim3(B), dim3(256), 0, s, st));
+        ShapeTermArgs st2{c->inv, c->P(D.sk_h2x), c->P(D.bk_h2x), c->P(D.sv_h2x), c->P(D.bv_h2x),
+                          c->add + ((size_t)l * 2 + 1) * c->capB * 4 * H, SL, H, SL};
+        LAUNCH("prep", hipLaunchKernelGGL(shape_term_kernel, dim3(B), dim3(256), 0, s, st2));
+        VnShapeArgs vs{d_shape, c->P(D.vn_f), c->P(D.vn_d), c->ps + (size_t)l * c->capB * 2 * hd * 3, S, hd};
+        LAUNCH("prep", hipLaunchKernelGGL(vn_shape_kernel, dim3(B), dim3(128), 0, s, vs));
+    }
+    return 0;
+}
+
+// One score evaluation on prepared batch data.  x_in/v_in: current state; outputs as given.
+template <int H>
+int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *v_in, int64_t N, int64_t B,
+              bool sampling, int t_first, float *out_pos, float *out_h, float *out_v) {
+    const shapemol_config &g = c->cfg;
+    const int L = g.num_layers, hd = g.n_heads, C = g.num_classes, D = g.time_emb_dim, KP = c->KP;
+    const int n = (int)N;
+    TimeEmbArgs te{c->P(c->dm.te1w), c->P(c->dm.te1b), c->P(c->dm.te2w), c->P(c->dm.te2b),
+                   sampling ? c->steps : nullptr, c->steps + 1, c->t_mol, c->temb, c->bn_acc, L * 2 * hd,
+                   (int)B, D, g.num_timesteps, t_first};
+    LAUNCH("embed", hipLaunchKernelGGL(time_embed_kernel, dim3((std::max<int64_t>(B, L * 2 * hd) + 63) / 64), dim3(64), 0, s, te));
+    AtomEmbArgs ae{c->P(c->dm.embw), c->P(c->dm.embb), v_in, c->mol_of, c->temb, c->h_a, n, H, C, D};
+    LAUNCH("embed", hipLaunchKernelGGL(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
+    LAUNCH("knn", hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x_in, c->mol_of, c->mol_off, n, g.knn, KP, c->nbr));
+    EdgeWeightArgs ea{x_in, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
+                      c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, n * KP, KP};
+    {
+        const int tiles = (n * KP + 15) / 16;
+        LAUNCH("edge_weight", hipLaunchKernelGGL(edge_weight_kernel<H>, dim3((tiles + 3) / 4), dim3(256), 0, s, ea));
+    }
+    const float *cur_x = x_in;
+    float *cur_h = c->h_a;
+    const int nlay = c->stop_layer >= 0 ? std::min(c->stop_layer, L) : L;
+    const dim3 ngrid2((N + 15) / 16, 2), ngrid1((N + 15) / 16, 1);
+    for (int l = 0; l < nlay; ++l) {
+        const DevLayer &Dl = c->dm.layer[l];
+        const bool last = (l == nlay - 1);
+        for (int half = 0; half < 2; ++half) {   // 0: x2h, 1: h2x
+            if (half == 1) {
+                // node_output MLP on [att | h] + residual -> new h
+                float *dst = (last && out_h) ? out_h : (cur_h == c->h_a ? c->h_b : c->h_a);
+                NodeArgs na{};
+                na.job[0] = mlp_job(c, Dl.no, c->att, cur_h, 2 * H, H, NODE_LN_RELU, H, cur_h, dst, H, H);
+                na.mol_of = c->mol_of; na.n_atoms = n;
+                LAUNCH("node_out", hipLaunchKernelGGL(node_mlp_kernel<H>, ngrid1, dim3(c->node_threads), 0, s, na));
+                cur_h = dst;
+            }
+            // per-node halves of the edge MLPs' first Linear + the query MLP
+            NodeArgs na{};
+            NodeJob &j0 = na.job[0];
+            j0.in0 = cur_h; j0.w1 = c->P(half ? Dl.pre_h2x : Dl.pre_x2h); j0.ldw1 = H; j0.n_out1 = 4 * H;
+            j0.add_mol = c->add + ((size_t)l * 2 + half) * c->capB * 4 * H; j0.mode = NODE_LINEAR;
+            j0.out = c->pre; j0.ld_out = 4 * H; j0.n_store = 4 * H;
+            na.job[1] = mlp_job(c, half ? Dl.q_h2x : Dl.q_x2h, cur_h, nullptr, H, H, NODE_LN_RELU, H, nullptr, c->q, H, H);
+            na.mol_of = c->mol_of; na.n_atoms = n;
+            LAUNCH("node_pre", hipLaunchKernelGGL(node_mlp_kernel<H>, ngrid2, dim3(c->node_threads), 0, s, na));
+            EdgeArgs e{c->P(half ? Dl.blob_h2x : Dl.blob_x2h), c->pre, c->q, cur_x, c->nbr, c->ew, half ? c->o3 : c->att, n};
+            if (half == 0) { if (launch_edge<H, false>(c, s, e)) return 1; }
+            else           { if (launch_edge<H, true>(c, s, e)) return 1; }
+        }
+        float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
+        VnArgs va{cur_x, c->o3, c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o),
+                  c->P(Dl.wd_o), c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * 2 * hd, x_next, n, hd};
+        const int per_blk = 256 / hd;
+        LAUNCH("vn_stats", hipLaunchKernelGGL(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
+        LAUNCH("vn_apply", hipLaunchKernelGGL(vn_apply_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
+        cur_x = x_next;
+    }
+    c->last_h = cur_h; c->last_x = cur_x;
+    if (nlay == 0 && out_pos) HIPCHK(hipMemcpyAsync(out_pos, x_in, N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_v) {
+        NodeArgs na{};
+        NodeJob &j = na.job[0];
+        j.in0 = cur_h; j.w1 = c->P(c->dm.v1w); j.b1 = c->P(c->dm.v1b); j.ldw1 = H; j.n_out1 = H; j.mode = NODE_SSP;
+        j.w2 = c->P(c->dm.v2w); j.b2 = c->P(c->dm.v2b); j.n_out2 = C; j.out = out_v; j.ld_out = C; j.n_store = C;
+        na.mol_of = c->mol_of; na.n_atoms = n;
+        LAUNCH("v_head", hipLaunchKernelGGL(node_mlp_kernel<H>, ngrid1, dim3(c->node_threads), 0, s, na));
+    }
+    return 0;
+}
+
+template <int H>
+int run_ddpm(shapemol_ctx *c, hipStream_t s, int64_t N, const float *d_eps, const float *d_u, uint64_t seed,
+             const shapemol_traj *tr) {
+    const shapemol_config &g = c->cfg;
+    DdpmArgs a{};
+    a.pred_pos = c->pred_pos; a.pred_v = c->pred_v; a.x_t = c->x_state; a.v_t = c->v_state; a.mol_of = c->mol_of;
+    a.t_mol = c->t_mol;
+    a.c0 = c->P(c->dm.tab[0]); a.ct = c->P(c->dm.tab[1]); a.logvar = c->P(c->dm.tab[2]); a.log_a = c->P(c->dm.tab[3]);
+    a.log_1ma = c->P(c->dm.tab[4]); a.log_abar = c->P(c->dm.tab[5]); a.log_1mabar = c->P(c->dm.tab[6]);
+    a.eps = d_eps; a.u = d_u; a.step_cur = c->steps + 1; a.step_ptr = c->steps; a.seed = seed;
+    a.x_next = c->x_state; a.v_next = c->v_state;
+    if (tr) { a.tr_pos = tr->pos_traj; a.tr_v = tr->v_traj; a.tr_v0 = tr->v0_traj; a.tr_vt = tr->vt_traj;
+              a.tr_pos_cond = tr->pos_cond_traj; a.tr_v_cond = tr->v_cond_traj; }
+    a.n_atoms = (int)N; a.C = g.num_classes;
+    LAUNCH("ddpm", hipLaunchKernelGGL(ddpm_step_kernel<32>, dim3((N + 127) / 128), dim3(128), 0, s, a));
+    return 0;
+}
+
+int check_cfg(const shapemol_config &g) {
+    if (g.hidden_dim != 128 && g.hidden_dim != 32) return fail("hidden_dim must be 128 (or 32 for the reduced test model)");
+    if (g.n_heads * 8 != g.hidden_dim) return fail("hidden_dim / n_heads must be 8");
+    if (g.num_r_gaussian != 20) return fail("num_r_gaussian must be 20 (fixed RBF centres)");
+    if (g.knn < 1 || g.knn > 32) return fail("knn must be in 1..32");
+    if (g.shape_dim < 1 || g.shape_dim > 64 || g.shape_latent_dim < 4 || g.shape_latent_dim > 64 || (g.shape_latent_dim & 3))
+        return fail("shape_dim must be 1..64, shape_latent_dim a multiple of 4 in 4..64");
+    if (g.time_emb_dim < 4 || g.time_emb_dim > 16 || (g.time_emb_dim & 1)) return fail("time_emb_dim must be even, 4..16");
+    if (g.num_classes < 2 || g.num_classes > 32) return fail("num_classes must be 2..32");
+    if (g.num_layers < 1 || g.num_timesteps < 1) return fail("num_layers / num_timesteps must be positive");
+    return 0;
+}
+
+#define DISPATCH_H(c, call128, call32) ((c)->cfg.hidden_dim == 128 ? (call128) : (call32))
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int shapemol_abi_version(void) { return SHAPEMOL_ABI_VERSION; }
+const char *shapemol_last_error(void) { return g_err.c_str(); }
+
+size_t shapemol_weight_count(const shapemol_config *cfg) { return cfg ? weight_count(*cfg) : 0; }
+
+int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_weights, int device, shapemol_ctx **out) {
+    if (!cfg || !weights || !out) return fail("shapemol_create: null argument");
+    if (check_cfg(*cfg)) return 1;
+    if (n_weights != weight_count(*cfg)) return fail("shapemol_create: weight count mismatch (got " + std::to_string(n_weights) + ", want " + std::to_string(weight_count(*cfg)) + ")");
+    HostModel hm;
+    if (!parse_weights(*cfg, weights, n_weights, hm)) return fail("shapemol_create: weight layout mismatch");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("shapemol_create: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    auto *c = new shapemol_ctx();
+    c->cfg = *cfg; c->device = device;
+    c->KP = cfg->knn <= 8 ? 8 : (cfg->knn <= 16 ? 16 : 32);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    const int H = cfg->hidden_dim, C = cfg->num_classes, T = cfg->num_timesteps;
+    Image im;
+    DevModel &dm = c->dm;
+    for (int i = 0; i < 7; ++i) dm.tab[i] = im.put(hm.tab[i], T);
+    dm.te1w = im.put(hm.te1.w, (size_t)hm.te1.out * hm.te1.in); dm.te1b = im.put(hm.te1.b, hm.te1.out);
+    dm.te2w = im.put(hm.te2.w, (size_t)hm.te2.out * hm.te2.in); dm.te2b = im.put(hm.te2.b, hm.te2.out);
+    dm.embw = im.put(hm.emb.w, (size_t)hm.emb.out * hm.emb.in); dm.embb = im.put(hm.emb.b, hm.emb.out);
+    auto put_mlp = [&](const Mlp &m) {
+        DevMlp d;
+        d.w1 = im.put(m.l1.w, (size_t)m.l1.out * m.l1.in); d.b1 = im.put(m.l1.b, m.l1.out);
+        d.g = im.put(m.g, m.l1.out); d.be = im.put(m.be, m.l1.out);
+        d.w2 = im.put(m.l2.w, (size_t)m.l2.out * m.l2.in); d.b2 = im.put(m.l2.b, m.l2.out);
+        return d;
+    };
+    dm.ew = put_mlp(hm.ew);
+    dm.inv = put_mlp(hm.inv);
+    dm.v1w = im.put(hm.v1.w, (size_t)H * H); dm.v1b = im.put(hm.v1.b, H);
+    dm.v2w = im.alloc((size_t)((C + 15) / 16) * 16 * H); std::memcpy(&im.d[dm.v2w], hm.v2.w, (size_t)C * H * sizeof(float));
+    dm.v2b = im.alloc(((C + 15) / 16) * 16); std::memcpy(&im.d[dm.v2b], hm.v2.b, C * sizeof(float));
+    dm.layer.resize(cfg->num_layers);
+    for (int l = 0; l < cfg->num_layers; ++l) {
+        if (H == 128) build_layer_image<128>(*cfg, hm.layer[l], im, dm.layer[l]);
+        else build_layer_image<32>(*cfg, hm.layer[l], im, dm.layer[l]);
+    }
+    im.alloc(64);
+    if (hipMalloc((void **)&c->d_img, im.d.size() * sizeof(float)) != hipSuccess) { delete c; return fail("hipMalloc(weights) failed"); }
+    if (hipMemcpy(c->d_img, im.d.data(), im.d.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { hipFree(c->d_img); delete c; return fail("hipMemcpy(weights) failed"); }
+    if (H == 128 ? set_edge_attr<128>(c->KP) : set_edge_attr<32>(c->KP)) { hipFree(c->d_img); delete c; return 1; }
+    *out = c;
+    return 0;
+}
+
+void shapemol_destroy(shapemol_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    if (c->gexec) hipGraphExecDestroy(c->gexec);
+    for (auto &r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (void *p : c->allocs) hipFree(p);
+    hipFree(c->d_img);
+    delete c;
+}
+
+int shapemol_reserve(shapemol_ctx *c, int64_t max_atoms, int64_t max_mols) {
+    if (!c || max_atoms < 1 || max_mols < 1) return fail("shapemol_reserve: bad argument");
+    return ensure_workspace(c, max_atoms, max_mols);
+}
+
+int shapemol_score(shapemol_ctx *c, const float *d_pos, const int64_t *d_v, const int64_t *d_batch, int64_t N,
+                   int64_t B, const float *d_shape, const int64_t *d_t, float *out_pos, float *out_h, float *out_v,
+                   void *stream) {
+    if (!c || !d_pos || !d_v || !d_batch || !d_shape || !d_t || !out_pos || !out_v) return fail("shapemol_score: null argument");
+    if (N < 1 || B < 1 || N > (1 << 27)) return fail("shapemol_score: n_atoms / n_mols out of range");
+    HIPCHK(hipSetDevice(c->device));
+    if (ensure_workspace(c, N, B)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    c->lastN = N; c->lastB = B;
+    if (DISPATCH_H(c, run_prep<128>(c, s, d_batch, N, B, d_shape), run_prep<32>(c, s, d_batch, N, B, d_shape))) return 1;
+    LAUNCH("prep", hipLaunchKernelGGL(t_convert_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d_t, (int)B, c->t_mol));
+    return DISPATCH_H(c, run_score<128>(c, s, d_pos, d_v, N, B, false, 0, out_pos, out_h, out_v),
+                      run_score<32>(c, s, d_pos, d_v, N, B, false, 0, out_pos, out_h, out_v));
+}
+
+int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_init_v, const int64_t *d_batch,
+                    int64_t N, int64_t B, const float *d_shape, int32_t num_steps, const float *d_eps, const float *d_u,
+                    uint64_t seed, const shapemol_traj *traj, float *out_pos, int64_t *out_v, int32_t use_graph, void *stream) {
+    if (!c || !d_init_pos || !d_init_v || !d_batch || !d_shape || !out_pos || !out_v) return fail("shapemol_sample: null argument");
+    if (N < 1 || B < 1 || N > (1 << 27)) return fail("shapemol_sample: n_atoms / n_mols out of range");
+    if (num_steps < 1 || num_steps > c->cfg.num_timesteps) return fail("shapemol_sample: num_steps out of range");
+    if ((d_eps == nullptr) != (d_u == nullptr)) return fail("shapemol_sample: d_eps and d_u must be given together");
+    HIPCHK(hipSetDevice(c->device));
+    if (ensure_workspace(c, N, B)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    c->lastN = N; c->lastB = B;
+    const int t_first = c->cfg.num_timesteps - 1;
+    if (DISPATCH_H(c, run_prep<128>(c, s, d_batch, N, B, d_shape), run_prep<32>(c, s, d_batch, N, B, d_shape))) return 1;
+    HIPCHK(hipMemcpyAsync(c->x_state, d_init_pos, N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->v_state, d_init_v, N * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemsetAsync(c->steps, 0, 4 * sizeof(int), s));
+    auto one_step = [&]() -> int {
+        if (DISPATCH_H(c, run_score<128>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v),
+                       run_score<32>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v))) return 1;
+        return DISPATCH_H(c, run_ddpm<128>(c, s, N, d_eps, d_u, seed, traj), run_ddpm<32>(c, s, N, d_eps, d_u, seed, traj));
+    };
+    if (use_graph && !c->prof_on) {
+        shapemol_ctx::GraphKey key{};
+        key.N = N; key.B = B; key.eps = d_eps; key.u = d_u; key.seed = seed; key.steps = 0;
+        if (traj) { key.tp[0] = traj->pos_traj; key.tp[1] = traj->v_traj; key.tp[2] = traj->v0_traj; key.tp[3] = traj->vt_traj; key.tp[4] = traj->pos_cond_traj; key.tp[5] = traj->v_cond_traj; }
+        if (!c->gexec || !(key == c->gkey)) {
+            if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int rc = one_step();
+            const hipError_t ce = hipStreamEndCapture(s, &graph);
+            if (rc) { if (graph) hipGraphDestroy(graph); return 1; }
+            if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            const hipError_t ie = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (ie != hipSuccess) { c->gexec = nullptr; return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+            c->gkey = key;
+        }
+        for (int st = 0; st < num_steps; ++st) HIPCHK(hipGraphLaunch(c->gexec, s));
+    } else {
+        for (int st = 0; st < num_steps; ++st) if (one_step()) return 1;
+    }
+    HIPCHK(hipMemcpyAsync(out_pos, c->x_state, N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(out_v, c->v_state, N * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int shapemol_log_sample_categorical(shapemol_ctx *c, const float *d_logits, const float *d_u, int64_t n_rows,
+                                    int32_t n_classes, uint64_t seed, int64_t *out_index, void *stream) {
+    if (!d_logits || !out_index || n_rows < 1 || n_classes < 1) return fail("shapemol_log_sample_categorical: bad argument");
+    if (c) HIPCHK(hipSetDevice(c->device));      // ctx may be NULL: the current device is used
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gumbel_argmax_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, d_logits, d_u, (int)n_rows, (int)n_classes, seed, out_index);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return fail("shapemol_set_option: null argument");
+    const std::string k(name);
+    if (k == "stop_layer") c->stop_layer = (int)value;
+    else if (k == "edge_waves") { if (value < 1 || value > 8) return fail("edge_waves must be 1..8"); c->edge_threads = (int)value * 64; }
+    else if (k == "node_waves") { if (value < 1 || value > 8) return fail("node_waves must be 1..8"); c->node_threads = (int)value * 64; }
+    else return fail("unknown option " + k);
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    return 0;
+}
+
+int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t max_bytes) {
+    if (!c || !name || !dst) { fail("shapemol_debug_read: null argument"); return -1; }
+    const std::string k(name);
+    const shapemol_config &g = c->cfg;
+    const int64_t N = c->lastN;
+    const void *src = nullptr; size_t bytes = 0;
+    int64_t dims[8] = {N, c->lastB, c->KP, g.hidden_dim, g.n_heads, g.num_layers, c->capN, c->capB};
+    if (k == "dims") { if (max_bytes < sizeof(dims)) return -1; std::memcpy(dst, dims, sizeof(dims)); return sizeof(dims); }
+    if (k == "nbr") { src = c->nbr; bytes = N * c->KP * 4; }
+    else if (k == "ew") { src = c->ew; bytes = N * c->KP * 4; }
+    else if (k == "h") { src = c->last_h; bytes = N * g.hidden_dim * 4; }
+    else if (k == "x") { src = c->last_x; bytes = N * 3 * 4; }
+    else if (k == "pre") { src = c->pre; bytes = N * 4 * g.hidden_dim * 4; }
+    else if (k == "q") { src = c->q; bytes = N * g.hidden_dim * 4; }
+    else if (k == "att") { src = c->att; bytes = N * g.hidden_dim * 4; }
+    else if (k == "o3") { src = c->o3; bytes = N * 48 * 4; }
+    else if (k == "bnstat") { src = c->bn_acc; bytes = (size_t)g.num_layers * 2 * g.n_heads * 8; }
+    else { fail("shapemol_debug_read: unknown buffer " + k); return -1; }
+    if (!src || bytes > max_bytes) { fail("shapemol_debug_read: buffer unavailable or destination too small"); return -1; }
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("shapemol_debug_read: copy failed"); return -1; }
+    return (int64_t)bytes;
+}
+
+int shapemol_profile_begin(shapemol_ctx *c) {
+    if (!c) return fail("shapemol_profile_begin: null ctx");
+    for (auto &r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    c->prof.clear();
+    c->prof_on = true;
+    return 0;
+}
+
+int shapemol_profile_end(shapemol_ctx *c, char (*names)[32], double *total_ms, int64_t *launches, int cap) {
+    if (!c) { fail("shapemol_profile_end: null ctx"); return -1; }
+    c->prof_on = false;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    std::vector<std::string> order;
+    std::map<std::string, std::pair<double, int64_t>> acc;
+    for (auto &r : c->prof) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (!acc.count(r.name)) order.push_back(r.name);
+        acc[r.name].first += ms; acc[r.name].second += 1;
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    c->prof.clear();
+    int n = 0;
+    for (auto &nm : order) {
+        if (n >= cap) break;
+        std::snprintf(names[n], 32, "%s", nm.c_str());
+        total_ms[n] = acc[nm].first; launches[n] = acc[nm].second; ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,492 @@
+// Small kernels around the attention layers: batch indexing, step-invariant shape terms,
+// time/atom embedding, kNN graph + edge weights, the vector-neuron coordinate update with
+// train-mode batch statistics, and the DDPM posterior step.
+#pragma once
+#include "sm_device.h"
+
+// ---------------------------------------------------------------------------------------------
+// batch (N,) i64 sorted -> mol_of (N,) i32 and mol_off (B+1,) i32
+// (reference: batch_ligand = repeat_interleave(arange(B), counts), scripts/sample_diffusion.py:72)
+// ---------------------------------------------------------------------------------------------
+__global__ void mol_index_kernel(const int64_t *batch, int n, int n_mols, int *mol_of, int *mol_off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = (int)batch[i];
+    mol_of[i] = b;
+    const int prev = i == 0 ? -1 : (int)batch[i - 1];
+    for (int m = prev + 1; m <= b; ++m) mol_off[m] = i;       // also covers empty molecules
+    if (i == n - 1)
+        for (int m = b + 1; m <= n_mols; ++m) mol_off[m] = n;
+}
+
+__global__ void t_convert_kernel(const int64_t *t, int n_mols, int *t_mol) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_mols) t_mol[i] = (int)t[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// InvariantShapeEmbLayer.forward (models/uni_transformer.py:181-189): one block per molecule.
+// ---------------------------------------------------------------------------------------------
+struct ShapeInvArgs {
+    const float *shape;              // [B][S][3]
+    const float *w1, *b1, *g, *be;   // Linear S->S, LayerNorm(S)
+    const float *w2, *b2;            // Linear S->SL
+    float *inv;                      // [B][SL]
+    int S, SL;
+};
+__global__ void shape_invariant_kernel(ShapeInvArgs a) {
+    __shared__ float raw[64], hid[64], red[4];
+    const int b = blockIdx.x, c = threadIdx.x, S = a.S;
+    const float *sh = a.shape + (size_t)b * S * 3;
+    if (c < 3) {
+        float m = 0.f;
+        for (int i = 0; i < S; ++i) m += sh[i * 3 + c];
+        red[c] = m / S;
+    }
+    __syncthreads();
+    if (c == 0) red[3] = red[0] * red[0] + red[1] * red[1] + red[2] * red[2] + 1e-6f;
+    __syncthreads();
+    if (c < S)
+        raw[c] = sh[c * 3] * (red[0] / red[3]) + sh[c * 3 + 1] * (red[1] / red[3]) + sh[c * 3 + 2] * (red[2] / red[3]);
+    __syncthreads();
+    float y = 0.f;
+    if (c < S) {
+        y = a.b1[c];
+        for (int i = 0; i < S; ++i) y += a.w1[c * S + i] * raw[i];
+    }
+    // LayerNorm over S values (S <= 64: one wave)
+    float s = c < S ? y : 0.f;
+    for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+    const float mean = s / S;
+    float q = c < S ? (y - mean) * (y - mean) : 0.f;
+    for (int m = 1; m < 64; m <<= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = 1.0f / sqrtf(q / S + 1e-5f);
+    if (c < S) hid[c] = fmaxf((y - mean) * rstd * a.g[c] + a.be[c], 0.f);
+    __syncthreads();
+    if (c < a.SL) {
+        float o = a.b2[c];
+        for (int i = 0; i < S; ++i) o += a.w2[c * S + i] * hid[i];
+        a.inv[(size_t)b * a.SL + c] = o;
+    }
+}
+
+// Step-invariant per-molecule term of the edge MLPs' first Linear:
+//   add[b][blk*H + f] = W1[f][G+2H : G+2H+SL] . inv_b + b1[f]   for the two "A" blocks (k: blk 0, v: blk 2)
+//   and 0 for the "B" blocks (1, 3).            (the inv_shape[dst] columns of kv_input, uni_transformer.py:61-63)
+struct ShapeTermArgs {
+    const float *inv;      // [B][SL]
+    const float *wk, *bk;  // W1 of the k MLP [H][ldw] (pointer already at column G+2H), bias [H]
+    const float *wv, *bv;
+    float *add;            // [B][4H]
+    int ldw, H, SL;
+};
+__global__ void shape_term_kernel(ShapeTermArgs a) {
+    const int b = blockIdx.x;
+    for (int f = threadIdx.x; f < 4 * a.H; f += blockDim.x) {
+        const int blk = f / a.H, ff = f % a.H;
+        float v = 0.f;
+        if ((blk & 1) == 0) {
+            const float *w = (blk == 0 ? a.wk : a.wv) + (size_t)ff * a.ldw;
+            v = (blk == 0 ? a.bk : a.bv)[ff];
+            for (int i = 0; i < a.SL; ++i) v += w[i] * a.inv[(size_t)b * a.SL + i];
+        }
+        a.add[(size_t)b * 4 * a.H + f] = v;
+    }
+}
+
+// Shape part of the VN-linear inputs (step-invariant): ps[b][which][c][dim] =
+//   sum_s W_which[c][1 + heads + s] * shape[b][s][dim]      (tmp_output concat, uni_transformer.py:154)
+struct VnShapeArgs {
+    const float *shape;    // [B][S][3]
+    const float *wf, *wd;  // [heads][1 + heads + S]
+    float *ps;             // [B][2][heads][3]
+    int S, heads;
+};
+__global__ void vn_shape_kernel(VnShapeArgs a) {
+    const int b = blockIdx.x, per = a.heads * 3, cin = 1 + a.heads + a.S;
+    for (int idx = threadIdx.x; idx < 2 * per; idx += blockDim.x) {
+        const int which = idx / per, c = (idx % per) / 3, dim = idx % 3;
+        const float *w = (which ? a.wd : a.wf) + (size_t)c * cin + 1 + a.heads;
+        float v = 0.f;
+        for (int s = 0; s < a.S; ++s) v += w[s] * a.shape[((size_t)b * a.S + s) * 3 + dim];
+        a.ps[(size_t)b * 2 * per + idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// time embedding (molopt_score_model.py:154-166,247-252) + per-step bookkeeping
+// ---------------------------------------------------------------------------------------------
+struct TimeEmbArgs {
+    const float *w1, *b1, *w2, *b2;  // Linear D->2D, Linear 2D->D
+    const int *step_ptr;             // sampling: device step counter (t = t_first-step); nullptr: use t_mol
+    int *step_cur;                   // stable copy of the counter for the rest of this step's kernels
+    int *t_mol;                      // [B]
+    float *temb;                     // [B][D]
+    double *bn_acc;                  // zeroed here at the start of every evaluation
+    int bn_acc_len;
+    int n_mols, D, T, t_first;       // t_first = T-1 for full chains
+};
+__global__ void time_embed_kernel(TimeEmbArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < a.bn_acc_len) a.bn_acc[b] = 0.0;
+    for (int i = b + gridDim.x * blockDim.x; i < a.bn_acc_len; i += gridDim.x * blockDim.x) a.bn_acc[i] = 0.0;
+    if (b == 0 && a.step_ptr) *a.step_cur = *a.step_ptr;
+    if (b >= a.n_mols) return;
+    int t;
+    if (a.step_ptr) { t = a.t_first - *a.step_ptr; a.t_mol[b] = t; } else { t = a.t_mol[b]; }
+    const int D = a.D, half = D / 2;
+    float e[16], hdn[32];
+    const float c = (float)(9.210340371976184 / (half - 1));    // ln(10000) / (half - 1)
+    for (int i = 0; i < half; ++i) {
+        const float fr = expf((float)i * -c);
+        const float arg = (float)t * fr;
+        e[i] = sinf(arg);
+        e[half + i] = cosf(arg);
+    }
+    for (int o = 0; o < 2 * D; ++o) {
+        float y = a.b1[o];
+        for (int i = 0; i < D; ++i) y += a.w1[o * D + i] * e[i];
+        hdn[o] = y / (1.0f + expf(-y));                            // SiLU
+    }
+    for (int o = 0; o < D; ++o) {
+        float y = a.b2[o];
+        for (int i = 0; i < 2 * D; ++i) y += a.w2[o * 2 * D + i] * hdn[i];
+        a.temb[(size_t)b * D + o] = y;
+    }
+}
+
+// ligand_atom_emb(cat[one_hot(v), time_emb[batch]])  (molopt_score_model.py:292-301)
+struct AtomEmbArgs {
+    const float *w, *b;     // [H][C + D], [H]
+    const int64_t *v;       // [N]
+    const int *mol_of;
+    const float *temb;      // [B][D]
+    float *h;               // [N][H]
+    int n_atoms, H, C, D;
+};
+__global__ void atom_embed_kernel(AtomEmbArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_atoms * a.H) return;
+    const int i = idx / a.H, f = idx % a.H, ld = a.C + a.D;
+    const float *w = a.w + (size_t)f * ld;
+    float y = a.b[f] + w[(int)a.v[i]];
+    const float *te = a.temb + (size_t)a.mol_of[i] * a.D;
+    for (int k = 0; k < a.D; ++k) y += w[a.C + k] * te[k];
+    a.h[idx] = y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kNN graph (uni_transformer.py:466-468; torch_geometric knn_graph semantics): one wave per
+// centre atom.  The rank of candidate c is the number of candidates of the same molecule with a
+// smaller (squared distance, index) key; rank < k selects slot `rank`.  The squared distance is
+// (dx*dx + dy*dy) + dz*dz with every operation rounded (no FMA contraction), the same
+// arithmetic as the oracle, so neighbour sets agree bit for bit.
+// ---------------------------------------------------------------------------------------------
+SM_DEV float dist2_rounded(float dx, float dy, float dz) {
+#pragma clang fp contract(off)
+    const float a = dx * dx, b = dy * dy, c = dz * dz;
+    return (a + b) + c;
+}
+
+__global__ void knn_kernel(const float *x, const int *mol_of, const int *mol_off, int n_atoms, int k,
+                           int kp, int *nbr) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n_atoms) return;
+    const int m = mol_of[i], s = mol_off[m], cnt = mol_off[m + 1] - s;
+    const float xi = x[i * 3], yi = x[i * 3 + 1], zi = x[i * 3 + 2];
+    const int deg = min(k, cnt - 1);
+    for (int c = lane; c < cnt; c += 64) {
+        const int j = s + c;
+        if (j == i) continue;
+        float dx = x[j * 3] - xi, dy = x[j * 3 + 1] - yi, dz = x[j * 3 + 2] - zi;
+        const float dc = dist2_rounded(dx, dy, dz);
+        int rank = 0;
+        for (int o = 0; o < cnt; ++o) {
+            const int jo = s + o;
+            dx = x[jo * 3] - xi; dy = x[jo * 3 + 1] - yi; dz = x[jo * 3 + 2] - zi;
+            const float d_o = dist2_rounded(dx, dy, dz);
+            rank += (jo != i) && (o != c) && (d_o < dc || (d_o == dc && o < c));
+        }
+        if (rank < k) nbr[(size_t)i * kp + rank] = j;
+    }
+    for (int sl = lane; sl < kp; sl += 64)
+        if (sl >= deg) nbr[(size_t)i * kp + sl] = -1;
+}
+
+// e_w = sigmoid(MLP_{G->H->1}(rbf(|x_i - x_j|)))   (uni_transformer.py:475-481), one 16-slot tile per wave
+struct EdgeWeightArgs {
+    const float *x;
+    const int *nbr;         // [N][KP]
+    const float *w1, *b1;   // [H][G], [H]
+    const float *g, *be;    // LayerNorm
+    const float *w2, *b2;   // [1][H], [1]
+    float *ew;              // [N][KP]
+    int n_slots, kp;        // n_slots = N * KP
+};
+template <int H>
+__global__ void __launch_bounds__(256)
+edge_weight_kernel(EdgeWeightArgs a) {
+    constexpr int NT = H / 16;
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int e_raw = tile * 16 + n;
+    if (tile * 16 >= a.n_slots) return;
+    const bool in_range = e_raw < a.n_slots;
+    const int e = in_range ? e_raw : a.n_slots - 1;
+    const int i = e / a.kp;
+    const int jraw = a.nbr[e];
+    const bool ok = in_range && jraw >= 0;
+    const int j = ok ? jraw : i;
+    const float r0 = a.x[i * 3] - a.x[j * 3], r1 = a.x[i * 3 + 1] - a.x[j * 3 + 1], r2 = a.x[i * 3 + 2] - a.x[j * 3 + 2];
+    float rb[5];
+    rbf_dlayout(sqrtf(r0 * r0 + r1 * r1 + r2 * r2), g, rb);
+    float hid[NT * 4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 b = ldg4(a.b1 + 16 * t + 4 * g);
+        f32x4 acc = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) acc = mfma16(a.w1[(16 * t + n) * 20 + 4 * s + g], rb[s], acc);
+        hid[4 * t] = acc[0]; hid[4 * t + 1] = acc[1]; hid[4 * t + 2] = acc[2]; hid[4 * t + 3] = acc[3];
+    }
+    ln_relu_dlayout<NT>(hid, a.g, a.be, g);
+    float p = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 w = ldg4(a.w2 + 16 * t + 4 * g);
+        p += w.x * hid[4 * t] + w.y * hid[4 * t + 1] + w.z * hid[4 * t + 2] + w.w * hid[4 * t + 3];
+    }
+    p = sum_groups(p) + a.b2[0];
+    if (g == 0 && in_range) a.ew[e] = ok ? 1.0f / (1.0f + expf(-p)) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vector-neuron coordinate update of BaseH2XAttLayer (uni_transformer.py:153-156) =
+// VNLinearLeakyReLU (shape_vn_layers.py:95-110) with VNBatchNorm in TRAIN mode (:50-61):
+// pass 1 computes p = W_f z, d = W_d z per atom and accumulates the batch sums of the vector
+// norms; pass 2 normalises with the batch mean / biased variance and updates x.
+// z = [x_i | o_i (heads vectors) | shape_b (S vectors)]; the shape part is pre-reduced (vn_shape_kernel).
+// o3 is stored with permuted head rows (row 4g + r, see sm_edge.h); `wf_o`/`wd_o` are permuted to match.
+// ---------------------------------------------------------------------------------------------
+struct VnArgs {
+    const float *x;         // [N][3]
+    const float *o3;        // [N][16][3]
+    const float *ps;        // [B][2][heads][3]
+    const float *wf_x, *wd_x;   // [heads]      column 0 of the VN weights
+    const float *wf_o, *wd_o;   // [heads][16]  columns of the attention rows (permuted, zero for padding rows)
+    const float *bn_g, *bn_b;   // [heads]
+    const int *mol_of;
+    float *pd;              // [N][heads][6]  p (3) and d (3)
+    double *acc;            // [2][heads]  sum of norms, sum of squared norms (this layer)
+    float *x_out;           // [N][3]
+    int n_atoms, heads;
+};
+
+// thread = (atom, channel c); blockDim = 256
+__global__ void vn_stats_kernel(VnArgs a) {
+    __shared__ double red[2][256];
+    const int heads = a.heads, per_blk = 256 / heads;
+    const int la = threadIdx.x / heads, c = threadIdx.x % heads;
+    const int i = blockIdx.x * per_blk + la;
+    double nv = 0.0, nv2 = 0.0;
+    if (la < per_blk && i < a.n_atoms) {
+        const float *o = a.o3 + (size_t)i * 48;
+        const float *psf = a.ps + ((size_t)a.mol_of[i] * 2 * heads + c) * 3;
+        const float *psd = psf + heads * 3;
+        float p[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float pp = a.wf_x[c] * a.x[i * 3 + k], dd = a.wd_x[c] * a.x[i * 3 + k];
+            for (int r = 0; r < 16; ++r) {
+                pp += a.wf_o[c * 16 + r] * o[r * 3 + k];
+                dd += a.wd_o[c * 16 + r] * o[r * 3 + k];
+            }
+            p[k] = pp + psf[k];
+            d[k] = dd + psd[k];
+        }
+        float *out = a.pd + ((size_t)i * heads + c) * 6;
+        out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
+        const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
+        nv = (double)nrm;
+        nv2 = (double)nrm * (double)nrm;
+    }
+    red[0][threadIdx.x] = nv;
+    red[1][threadIdx.x] = nv2;
+    __syncthreads();
+    if (threadIdx.x < heads) {
+        double s = 0.0, s2 = 0.0;
+        for (int k = 0; k < per_blk; ++k) { s += red[0][k * heads + threadIdx.x]; s2 += red[1][k * heads + threadIdx.x]; }
+        atomicAdd(a.acc + threadIdx.x, s);
+        atomicAdd(a.acc + heads + threadIdx.x, s2);
+    }
+}
+
+__global__ void vn_apply_kernel(VnArgs a) {
+    __shared__ float red[256][3];
+    const int heads = a.heads, per_blk = 256 / heads;
+    const int la = threadIdx.x / heads, c = threadIdx.x % heads;
+    const int i = blockIdx.x * per_blk + la;
+    const bool ok = la < per_blk && i < a.n_atoms;
+    float o[3] = {0.f, 0.f, 0.f};
+    if (ok) {
+        const double cnt = (double)a.n_atoms;
+        const double mean = a.acc[c] / cnt;
+        double var = a.acc[heads + c] / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float meanf = (float)mean;
+        const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+        const float *pd = a.pd + ((size_t)i * heads + c) * 6;
+        float p[3] = {pd[0], pd[1], pd[2]};
+        const float d[3] = {pd[3], pd[4], pd[5]};
+        const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
+        const float nbn = (nrm - meanf) * rstd * a.bn_g[c] + a.bn_b[c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = p[k] / nrm * nbn;
+        const float dot = p[0] * d[0] + p[1] * d[1] + p[2] * d[2];
+        const float dsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        const float coef = dot / (dsq + 1e-6f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float neg = p[k] - coef * d[k];
+            o[k] = 0.2f * p[k] + 0.8f * (dot >= 0.f ? p[k] : neg);
+        }
+    }
+    red[threadIdx.x][0] = o[0]; red[threadIdx.x][1] = o[1]; red[threadIdx.x][2] = o[2];
+    __syncthreads();
+    if (ok && c < 3) {
+        float res = 0.f, att = 0.f;
+        for (int h = 0; h < heads; ++h) res += red[la * heads + h][c];
+        const float *ob = a.o3 + (size_t)i * 48;
+        for (int r = 0; r < 16; ++r) att += ob[r * 3 + c];          // padding rows are zero
+        a.x_out[i * 3 + c] = a.x[i * 3 + c] + (att / heads + res / heads);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// DDPM posterior step (molopt_score_model.py:653-681): q_pos_posterior (:400-404) + noise,
+// log_softmax, index_to_log_onehot (:64-68), q_v_posterior (:377-385) with the uniform mixing
+// of q_v_pred / q_v_pred_one_timestep (:323-364), Gumbel-argmax sampling (:98-104).
+// ---------------------------------------------------------------------------------------------
+struct DdpmArgs {
+    const float *pred_pos;   // [N][3]
+    const float *pred_v;     // [N][C]
+    const float *x_t;        // [N][3]
+    const int64_t *v_t;      // [N]
+    const int *mol_of;
+    const int *t_mol;        // [B]
+    const float *c0, *ct, *logvar, *log_a, *log_1ma, *log_abar, *log_1mabar;   // [T] tables
+    const float *eps, *u;    // host-fed noise of ALL steps ([S][N][3], [S][N][C]) or nullptr
+    const int *step_cur;     // this step's index (written by time_embed_kernel) or nullptr (= 0)
+    int *step_ptr;           // device step counter, advanced here for the NEXT step (nobody reads it in this kernel)
+    uint64_t seed;
+    float *x_next;           // [N][3]
+    int64_t *v_next;         // [N]
+    float *tr_pos; int64_t *tr_v; float *tr_v0; float *tr_vt; float *tr_pos_cond; float *tr_v_cond;  // trajectories or nullptr
+    int n_atoms, C;
+};
+template <int MAXC>
+__global__ void ddpm_step_kernel(DdpmArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int step = a.step_cur ? *a.step_cur : 0;
+    if (i < a.n_atoms) {
+        const int C = a.C;
+        const int t = a.t_mol[a.mol_of[i]];
+        const size_t so = (size_t)step * a.n_atoms + i;
+        float e3[3], uu[MAXC];
+        if (a.eps) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e3[k] = a.eps[so * 3 + k];
+            for (int c = 0; c < C; ++c) uu[c] = a.u[so * C + c];
+        } else {
+            Philox ph{(uint32_t)a.seed, (uint32_t)(a.seed >> 32)};
+            uint32_t r[4];
+            ph((uint32_t)i, (uint32_t)step, 0u, 0x5eedu, r);
+            const float r0 = sqrtf(-2.0f * logf(u01_open(r[0]))), r1 = sqrtf(-2.0f * logf(u01_open(r[2])));
+            e3[0] = r0 * cosf(6.283185307179586f * u01_half(r[1]));
+            e3[1] = r0 * sinf(6.283185307179586f * u01_half(r[1]));
+            e3[2] = r1 * cosf(6.283185307179586f * u01_half(r[3]));
+            for (int c0 = 0; c0 < C; c0 += 4) {
+                ph((uint32_t)i, (uint32_t)step, (uint32_t)(1 + c0 / 4), 0x5eedu, r);
+                for (int k = 0; k < 4 && c0 + k < C; ++k) uu[c0 + k] = u01_half(r[k]);
+            }
+        }
+        // ---- positions
+        const float c0 = a.c0[t], ct = a.ct[t];
+        const float sig = t != 0 ? expf(0.5f * a.logvar[t]) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float pp = a.pred_pos[i * 3 + k];
+            const float xn = (c0 * pp + ct * a.x_t[i * 3 + k]) + sig * e3[k];
+            a.x_next[i * 3 + k] = xn;
+            if (a.tr_pos) a.tr_pos[so * 3 + k] = xn;
+            if (a.tr_pos_cond) a.tr_pos_cond[so * 3 + k] = pp;
+        }
+        // ---- atom types
+        float lg[MAXC];
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) { lg[c] = a.pred_v[(size_t)i * C + c]; mx = fmaxf(mx, lg[c]); }
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(lg[c] - mx);
+        const float lse = mx + logf(se);
+        const int tm1 = t > 0 ? t - 1 : 0;
+        const float logC = logf((float)C);
+        const float la_prev = a.log_abar[tm1], l1_prev = a.log_1mabar[tm1] - logC;
+        const float la_t = a.log_a[t], l1_t = a.log_1ma[t] - logC;
+        const int vt = (int)a.v_t[i];
+        float un[MAXC];
+        float umx = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            const float lv0 = lg[c] - lse;
+            if (a.tr_v_cond) a.tr_v_cond[so * C + c] = lg[c];
+            if (a.tr_v0) a.tr_v0[so * C + c] = lv0;
+            const float A1 = lv0 + la_prev;
+            const float m1 = fmaxf(A1, l1_prev);
+            const float q1 = m1 + logf(expf(A1 - m1) + expf(l1_prev - m1));
+            const float lvt = (c == vt ? 0.f : -69.07755278982137f) + la_t;   // log(clamp(onehot, 1e-30))
+            const float m2 = fmaxf(lvt, l1_t);
+            const float q2 = m2 + logf(expf(lvt - m2) + expf(l1_t - m2));
+            un[c] = q1 + q2;
+            umx = fmaxf(umx, un[c]);
+        }
+        float us = 0.f;
+        for (int c = 0; c < C; ++c) us += expf(un[c] - umx);
+        const float ulse = umx + logf(us);
+        int best = 0;
+        float bestv = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            const float lp = un[c] - ulse;
+            if (a.tr_vt) a.tr_vt[so * C + c] = lp;
+            const float gum = -logf(-logf(uu[c] + 1e-30f) + 1e-30f);
+            const float sc = gum + lp;
+            if (sc > bestv) { bestv = sc; best = c; }
+        }
+        a.v_next[i] = best;
+        if (a.tr_v) a.tr_v[so] = best;
+    }
+    if (a.step_ptr && blockIdx.x == 0 && threadIdx.x == 0) *a.step_ptr = step + 1;
+}
+
+// log_sample_categorical (molopt_score_model.py:98-104)
+__global__ void gumbel_argmax_kernel(const float *logits, const float *u, int n, int C, uint64_t seed, int64_t *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Philox ph{(uint32_t)seed, (uint32_t)(seed >> 32)};
+    int best = 0;
+    float bestv = -INFINITY;
+    uint32_t r[4];
+    for (int c = 0; c < C; ++c) {
+        float uc;
+        if (u) uc = u[(size_t)i * C + c];
+        else { if ((c & 3) == 0) ph((uint32_t)i, 0xFFFFFFFFu, (uint32_t)(c >> 2), 0xca7u, r); uc = u01_half(r[c & 3]); }
+        const float sc = -logf(-logf(uc + 1e-30f) + 1e-30f) + logits[(size_t)i * C + c];
+        if (sc > bestv) { bestv = sc; best = c; }
+    }
+    out[i] = best;
+}
+
+__global__ void copy_state_kernel(const float *x_src, const int64_t *v_src, float *x_dst, int64_t *v_dst, int n_atoms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_atoms * 3 && x_dst) x_dst[i] = x_src[i];
+    if (i < n_atoms && v_dst) v_dst[i] = v_src[i];
+}

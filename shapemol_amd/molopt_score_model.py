@@ -1,0 +1,282 @@
+"""Drop-in host module for the reference's ``models/molopt_score_model.py`` hot path.
+
+Same call surface as the reference (paths relative to the reference repository):
+  * ``ScorePosNet3D(config, ligand_atom_feature_dim)``        models/molopt_score_model.py:171
+    -- same state-dict keys (446 for the shipped config), so ``load_state_dict(ckpt['model'])``
+       works unchanged (scripts/sample_diffusion.py:211-215)
+  * ``.forward(ligand_pos_perturbed, ligand_v_perturbed, batch_ligand, ligand_shape, time_step, return_all)``
+                                                              models/molopt_score_model.py:286-320
+  * ``.sample_diffusion(init_ligand_pos, init_ligand_v, batch_ligand, ligand_shape, ...)``
+                                                              models/molopt_score_model.py:533-697
+  * ``log_sample_categorical(logits)``                        models/molopt_score_model.py:98-104
+
+All arithmetic runs in libshapemol_hip.so (hand-written HIP for gfx950) through the C ABI of
+``include/shapemol_hip.h``; torch only owns device memory and streams here.  As in the
+reference's sampling script the module is used in *train mode* semantics: the VN batch-norm
+always normalises with the statistics of the current batch; ``eval()`` does not
+change that, and running statistics are not updated.
+There is no CPU path: tensors must live on a HIP device and the library must be built.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .diffusion import build_schedule_tables
+from .packing import pack_state_dict
+from .spec import ModelDims, state_dict_spec, RBF_CENTRES
+
+__all__ = ["ScorePosNet3D", "log_sample_categorical"]
+
+
+class _Params(nn.Module):
+    """A bare container; sub-modules and parameters are attached by name to reproduce the
+    reference's state-dict keys without reproducing its classes."""
+
+
+def _attach(root, key, tensor, kind):
+    parts = key.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Params())
+        mod = mod._modules[p]
+    leaf = parts[-1]
+    if kind in ("running_mean", "running_var", "counter") or leaf == "offset":
+        mod.register_buffer(leaf, tensor)
+    else:
+        mod.register_parameter(leaf, nn.Parameter(tensor, requires_grad=(kind != "const")))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream_ptr(stream):
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _check_device_tensor(name, t, dtype):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a tensor on a HIP device (shapemol_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+class ScorePosNet3D(nn.Module):
+
+    def __init__(self, config, ligand_atom_feature_dim):
+        super().__init__()
+        self.config = config
+        self.dims = ModelDims(config, ligand_atom_feature_dim)
+        g = (config.get if hasattr(config, "get") else lambda k, d=None: getattr(config, k, d))
+        self.denoise_type = g("denoise_type")
+        self.model_mean_type = g("model_mean_type")
+        self.loss_v_weight = g("loss_v_weight")
+        self.loss_weight_type = g("loss_weight_type")
+        self.v_mode = g("v_mode")
+        self.v_net_type = g("v_net_type", "mlp") or "mlp"
+        self.sample_time_method = g("sample_time_method")
+        self.loss_pos_type = g("loss_pos_type")
+        self.hidden_dim = self.dims.H
+        self.num_classes = self.dims.C
+        self.center_pos_mode = g("center_pos_mode")
+        self.time_emb_dim = self.dims.temb
+        self.refine_net_type = g("model_type")
+        self.cond_mask_prob = g("cond_mask_prob")
+
+        tables = build_schedule_tables(config)
+        gen = torch.Generator().manual_seed(0)
+        for key, (shape, kind, fan_in) in state_dict_spec(self.dims).items():
+            if kind == "const":
+                arr = np.asarray(RBF_CENTRES, np.float32) if key.endswith("offset") else tables[key]
+                t = torch.from_numpy(np.array(arr, dtype=np.float32))
+            elif kind == "counter":
+                t = torch.zeros(shape, dtype=torch.long)
+            elif kind in ("running_mean", "norm_bias"):
+                t = torch.zeros(shape)
+            elif kind in ("running_var", "norm_weight"):
+                t = torch.ones(shape)
+            else:   # Linear weight / bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in)), torch.nn.Linear's default range
+                bound = 1.0 / np.sqrt(fan_in)
+                t = (torch.rand(shape, generator=gen) * 2 - 1) * bound
+            _attach(self, key, t, kind)
+        self.num_timesteps = self.dims.T
+        self._ctx = None
+        self._ctx_key = None
+
+    # ------------------------------------------------------------------ library context
+    def _weights_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _context(self, device):
+        """Create (or refresh after a weight change / device move) the library context."""
+        key = self._weights_key(device)
+        if self._ctx is not None and key == self._ctx_key:
+            return self._ctx
+        lib = _lib.load()
+        self._release()
+        d = self.dims
+        cfg = _lib.Config(d.H, d.heads, d.L, d.k, d.G, d.S, d.S_latent, d.temb, d.C, d.T)
+        packed = pack_state_dict(self.state_dict(), d.L)
+        want = lib.shapemol_weight_count(C.byref(cfg))
+        if packed.size != want:
+            raise _lib.ShapeMolLibraryError(f"packed weight count {packed.size} != library's {want}")
+        ctx = C.c_void_p()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        _lib.check(lib.shapemol_create(C.byref(cfg), packed.ctypes.data_as(C.c_void_p), packed.size, index, C.byref(ctx)),
+                   "shapemol_create")
+        self._ctx, self._ctx_key = ctx, key
+        return ctx
+
+    def _release(self):
+        if getattr(self, "_ctx", None) is not None:
+            _lib.load().shapemol_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def set_option(self, name, value):
+        """Library tuning / diagnostics knob (see shapemol_set_option)."""
+        dev = next(self.parameters()).device
+        _lib.check(_lib.load().shapemol_set_option(self._context(dev), name.encode(), int(value)), "shapemol_set_option")
+
+    def debug_read(self, name, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        n = _lib.load().shapemol_debug_read(self._ctx, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes)
+        if n != out.nbytes:
+            raise _lib.ShapeMolLibraryError(f"debug_read({name}): got {n} bytes, want {out.nbytes}")
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, ligand_pos_perturbed, ligand_v_perturbed, batch_ligand, ligand_shape, time_step=None,
+                return_all=False):
+        """f(x0, v0 | xt, vt): one score evaluation.  Returns the reference's dict
+        {'pred_ligand_pos' (N,3), 'pred_ligand_h' (N,H), 'pred_ligand_v' (N,C)}."""
+        if return_all:
+            raise NotImplementedError("return_all=True (per-block outputs) is not part of the accelerated path")
+        if time_step is None:
+            raise ValueError("time_step is required (time_emb_dim > 0)")
+        pos = _check_device_tensor("ligand_pos_perturbed", ligand_pos_perturbed, torch.float32)
+        v = _check_device_tensor("ligand_v_perturbed", ligand_v_perturbed, torch.int64)
+        batch = _check_device_tensor("batch_ligand", batch_ligand, torch.int64)
+        shape = _check_device_tensor("ligand_shape", ligand_shape, torch.float32).view(-1, self.dims.S, 3)
+        t = _check_device_tensor("time_step", time_step, torch.int64)
+        n, b = pos.shape[0], shape.shape[0]
+        if v.shape[0] != n or batch.shape[0] != n or t.shape[0] != b or pos.shape[1] != 3:
+            raise ValueError("inconsistent input shapes")
+        dev = pos.device
+        ctx = self._context(dev)
+        out_pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        out_h = torch.empty((n, self.dims.H), dtype=torch.float32, device=dev)
+        out_v = torch.empty((n, self.dims.C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().shapemol_score(ctx, _ptr(pos), _ptr(v), _ptr(batch), n, b, _ptr(shape), _ptr(t),
+                                            _ptr(out_pos), _ptr(out_h), _ptr(out_v),
+                                            _stream_ptr(torch.cuda.current_stream(dev)))
+        _lib.check(rc, "shapemol_score")
+        return {"pred_ligand_pos": out_pos, "pred_ligand_h": out_h, "pred_ligand_v": out_v}
+
+    # ------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample_diffusion(self, init_ligand_pos, init_ligand_v, batch_ligand, ligand_shape, threshold_type=None,
+                         threshold_args=None, num_steps=None, center_pos_mode=None, use_grad=False, grad_lr=1,
+                         shape_AE=None, use_mesh_data=None, use_pointcloud_data=None, grad_step=500,
+                         guide_stren=0, bounds=None, *, noise=None, seed=None, return_traj=True, use_graph=True):
+        """Reverse diffusion chain; same arguments and result dict as the reference.
+
+        Extensions (keyword-only): ``noise=(eps, u)`` feeds host-chosen draws, eps (S,N,3) and u (S,N,C)
+        device tensors in the reference's per-step order; otherwise device Philox noise keyed by
+        ``seed`` (default: drawn from torch's CPU generator, so ``torch.manual_seed`` governs it).
+        ``return_traj=False`` skips the per-step trajectories (the lists come back empty).
+        """
+        if use_mesh_data is not None or use_pointcloud_data is not None or use_grad:
+            raise NotImplementedError("mesh / point-cloud / gradient shape guidance is outside the accelerated path")
+        if self.cond_mask_prob == 0:
+            assert guide_stren == 0
+        if guide_stren:
+            raise NotImplementedError("classifier-free guidance is unreachable in the reference (SURVEY.md F10)")
+        if center_pos_mode not in (None, "none"):
+            raise NotImplementedError("center_pos_mode != 'none'")
+        if num_steps is None:
+            num_steps = self.num_timesteps
+        print('sample center pos mode: ', center_pos_mode)
+
+        pos = _check_device_tensor("init_ligand_pos", init_ligand_pos, torch.float32)
+        v = _check_device_tensor("init_ligand_v", init_ligand_v, torch.int64)
+        batch = _check_device_tensor("batch_ligand", batch_ligand, torch.int64)
+        shape = _check_device_tensor("ligand_shape", ligand_shape, torch.float32).view(-1, self.dims.S, 3)
+        n, b, cc, dev = pos.shape[0], shape.shape[0], self.dims.C, pos.device
+        ctx = self._context(dev)
+        lib = _lib.load()
+        eps = u = None
+        if noise is not None:
+            eps = _check_device_tensor("noise[0]", noise[0], torch.float32)
+            u = _check_device_tensor("noise[1]", noise[1], torch.float32)
+            if tuple(eps.shape) != (num_steps, n, 3) or tuple(u.shape) != (num_steps, n, cc):
+                raise ValueError("noise must be (eps (S,N,3), u (S,N,C))")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        tr = _lib.Traj()
+        bufs = {}
+        if return_traj:
+            for name, shp, dt in (("pos_traj", (num_steps, n, 3), torch.float32), ("v_traj", (num_steps, n), torch.int64),
+                                  ("v0_traj", (num_steps, n, cc), torch.float32), ("vt_traj", (num_steps, n, cc), torch.float32),
+                                  ("pos_cond_traj", (num_steps, n, 3), torch.float32),
+                                  ("v_cond_traj", (num_steps, n, cc), torch.float32)):
+                bufs[name] = torch.empty(shp, dtype=dt, device=dev)
+                setattr(tr, name, bufs[name].data_ptr())
+        out_pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        out_v = torch.empty((n,), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            # hipGraph capture is not allowed on the legacy default stream: run the chain on a side stream
+            side = self._side_stream(dev)
+            side.wait_stream(cur)
+            rc = lib.shapemol_sample(ctx, _ptr(pos), _ptr(v), _ptr(batch), n, b, _ptr(shape), int(num_steps),
+                                     _ptr(eps), _ptr(u), C.c_uint64(seed), C.byref(tr), _ptr(out_pos), _ptr(out_v),
+                                     1 if use_graph else 0, _stream_ptr(side))
+            cur.wait_stream(side)
+        _lib.check(rc, "shapemol_sample")
+        for t_ in (pos, v, batch, shape, eps, u, out_pos, out_v, *bufs.values()):
+            if t_ is not None:
+                t_.record_stream(side)
+        res = {"pos": out_pos, "v": out_v, "pos_uncond_traj": [], "v_uncond_traj": []}
+        if return_traj:
+            host = {k: bufs[k].cpu() for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj")}
+            res.update(pos_traj=list(host["pos_traj"].unbind(0)), v_traj=list(host["v_traj"].unbind(0)),
+                       v0_traj=list(host["v0_traj"].unbind(0)), vt_traj=list(host["vt_traj"].unbind(0)),
+                       pos_cond_traj=list(bufs["pos_cond_traj"].unbind(0)), v_cond_traj=list(bufs["v_cond_traj"].unbind(0)))
+        else:
+            res.update(pos_traj=[], v_traj=[], v0_traj=[], vt_traj=[], pos_cond_traj=[], v_cond_traj=[])
+        return res
+
+    def _side_stream(self, dev):
+        s = getattr(self, "_stream", None)
+        if s is None or s.device != dev:
+            s = torch.cuda.Stream(device=dev)
+            self._stream = s
+        return s
+
+
+def log_sample_categorical(logits, *, u=None, seed=None):
+    """Gumbel-argmax categorical sample of each row of ``logits`` (device tensor) -> LongTensor."""
+    lg = _check_device_tensor("logits", logits, torch.float32)
+    n, c = lg.shape
+    if u is not None:
+        u = _check_device_tensor("u", u, torch.float32)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    out = torch.empty((n,), dtype=torch.int64, device=lg.device)
+    with torch.cuda.device(lg.device):
+        rc = _lib.load().shapemol_log_sample_categorical(None, _ptr(lg), _ptr(u), n, c, C.c_uint64(seed), _ptr(out),
+                                                         _stream_ptr(torch.cuda.current_stream(lg.device)))
+    _lib.check(rc, "shapemol_log_sample_categorical")
+    return out

@@ -1,0 +1,112 @@
+"""Host logic that needs no GPU: schedules, state-dict layout, deterministic inputs, packing,
+and that the C-ABI library loads and exports every symbol the header declares."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN, ROOT, golden, model_cfg, synth
+
+
+def test_schedule_known_answers():
+    """SURVEY.md section 4 known answers + exact agreement with the reference's tables."""
+    from shapemol_amd.diffusion import build_schedule_tables
+    tab = build_schedule_tables(model_cfg())
+    idx = [0, 1, 500, 998, 999]
+    np.testing.assert_allclose(tab["betas"][idx], [2.48259839e-05, 2.51240363e-05, 5.01506496e-03, 9.97497607e-03, 9.97527409e-03], rtol=2e-7)
+    np.testing.assert_allclose(tab["alphas_cumprod"][idx], [0.999975145, 0.999950051, 0.559409797, 6.66417694e-03, 6.59770006e-03], rtol=2e-7)
+    np.testing.assert_allclose(tab["posterior_logvar"][idx], [-11.2908049, -11.2908049, -5.3017292, -4.60774326, -4.60771275], rtol=2e-7)
+    np.testing.assert_allclose(tab["log_alphas_cumprod_v"][idx], [-5.07989789e-05, -1.06436943e-04, -0.711743474, -12.9320049, -19.8397598], rtol=2e-7)
+    g = golden("schedules.npz")
+    assert set(g.files) == set(tab)
+    for k in g.files:
+        assert np.array_equal(tab[k], g[k]), k
+
+
+def test_state_dict_layout_matches_reference():
+    from shapemol_amd.spec import ModelDims, state_dict_spec
+    spec = state_dict_spec(ModelDims(model_cfg(), 15))
+    layout = json.load(open(os.path.join(GOLDEN, "state_dict_layout.json")))
+    assert [e[0] for e in layout] == list(spec)
+    for key, shape, dtype, kind, fan_in in layout:
+        s = spec[key]
+        assert list(s[0]) == shape and s[1] == kind and s[2] == fan_in, key
+    assert len(spec) == 446
+
+
+def test_module_accepts_reference_state_dict():
+    import shapemol_amd
+    m = shapemol_amd.ScorePosNet3D(model_cfg(), 15)
+    layout = json.load(open(os.path.join(GOLDEN, "state_dict_layout.json")))
+    sd = m.state_dict()
+    assert set(sd) == {e[0] for e in layout}
+    for key, shape, dtype, _, _ in layout:
+        assert list(sd[key].shape) == shape and str(sd[key].dtype) == "torch." + dtype, key
+    assert sum(v.numel() for v in sd.values()) == 2673421
+    sdn = synth.synthetic_state_dict(model_cfg(), seed=7)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+    assert m.num_classes == 15 and m.v_mode == "uniform" and m.num_timesteps == 1000 and m.cond_mask_prob == 0.0
+    g = golden("schedules.npz")
+    for k in g.files:
+        assert np.array_equal(m.state_dict()[k].numpy(), g[k]), k
+
+
+def test_unsupported_configs_raise():
+    import shapemol_amd
+    for ov in (dict(v_mode="tomask"), dict(cutoff_mode="radius"), dict(topo_emb_type="topo_layer"), dict(num_blocks=2)):
+        with pytest.raises(NotImplementedError):
+            shapemol_amd.ScorePosNet3D(model_cfg(**ov), 15)
+
+
+def test_synth_is_deterministic():
+    a = synth.synthetic_batch(16, seed=3)
+    b = synth.synthetic_batch(16, seed=3)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    assert a["counts"].min() >= 9 and a["counts"].max() <= 27
+    assert np.array_equal(a["batch"], np.repeat(np.arange(16), a["counts"]))
+    e, u = synth.step_noise(10, 15, 3, seed=1)
+    assert e.shape == (10, 3) and u.shape == (10, 15) and (u >= 0).all() and (u < 1).all()
+    # pinned values: any change of the generator invalidates the golden chains
+    np.testing.assert_array_equal(synth.hash_u24(4, 5, 6), np.array(synth.hash_u24(4, 5, 6)))
+    z = synth.hash_normal((20000,), 1, 2)
+    assert abs(float(z.mean())) < 0.03 and abs(float(z.std()) - 1.0) < 0.03
+
+
+def test_library_exports_every_header_symbol():
+    from shapemol_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "shapemol_hip.h")).read()
+    declared = set(re.findall(r"\b(shapemol_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.shapemol_abi_version() == 1
+
+
+def test_pack_matches_library_weight_count():
+    from shapemol_amd import _lib, pack_state_dict
+    lib = _lib.load()
+    for ov, dims in ((dict(), (128, 16, 8, 8)), (dict(hidden_dim=32, n_heads=4, num_layers=2), (32, 4, 2, 8))):
+        cfg = model_cfg(**ov)
+        sdn = synth.synthetic_state_dict(cfg, seed=1)
+        packed = pack_state_dict(sdn, cfg["num_layers"])
+        c = _lib.Config(dims[0], dims[1], dims[2], dims[3], 20, 32, 32, 8, 15, 1000)
+        assert packed.size == lib.shapemol_weight_count(C.byref(c))
+        assert packed.dtype == np.float32
+
+
+def test_no_cpu_fallback():
+    import shapemol_amd
+    m = shapemol_amd.ScorePosNet3D(model_cfg(), 15)
+    z = torch.zeros
+    with pytest.raises(RuntimeError):
+        m(z(3, 3), z(3, dtype=torch.long), z(3, dtype=torch.long), z(1, 32, 3), z(1, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        m.sample_diffusion(z(3, 3), z(3, dtype=torch.long), z(3, dtype=torch.long), z(1, 96), num_steps=2)
+    with pytest.raises(RuntimeError):
+        shapemol_amd.log_sample_categorical(z(3, 15))

@@ -1,0 +1,80 @@
+"""The CPU oracle against the golden vectors produced by the imported reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from util import O, T, golden, maxabs, oracle_model, hash_noise, synth
+
+FWD_TOL = 5e-6     # float32 forward, values up to ~4: summation-order noise only
+
+
+@pytest.mark.parametrize("name", ["t999", "t500", "t0", "tmix"])
+def test_forward_b4(name):
+    sd, dm, _, _ = oracle_model()
+    f = golden("forward_b4.npz")
+    taps = {}
+    out = O.score(sd, dm, T(f["pos"]), T(f["v"]), T(f["batch"]), T(f["shape"]), T(f[name + "_t"]), taps)
+    for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+        assert maxabs(out[k], f[f"{name}_{k}"]) < FWD_TOL, k
+    if name == "t999":   # per-stage taps recorded by hooks on the reference's own sub-modules
+        assert np.array_equal(taps["edge_index"].numpy(), f["t999_edge_index"])
+        assert maxabs(taps["e_w"], 1 / (1 + np.exp(-f["t999_ew_logit"].astype(np.float64)))) < 1e-6
+        for l in range(dm.L):
+            assert maxabs(taps[f"h_{l}"], f[f"t999_h_{l}"]) < FWD_TOL
+            assert maxabs(taps[f"dx_{l}"], f[f"t999_dx_{l}"]) < FWD_TOL
+            assert maxabs(taps[f"bn_in_{l}"], f[f"t999_bn_in_{l}"]) < FWD_TOL
+
+
+def test_forward_ragged():
+    """molecules of 1, 2, 5, 9, 30, 3 atoms: fewer than k neighbours, and an atom with none."""
+    sd, dm, _, _ = oracle_model()
+    f = golden("forward_ragged.npz")
+    out = O.score(sd, dm, T(f["pos"]), T(f["v"]), T(f["batch"]), T(f["shape"]), T(f["t"]))
+    for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+        assert maxabs(out[k], f[k]) < FWD_TOL, k
+
+
+@pytest.mark.parametrize("tag", ["small", "k32"])
+def test_forward_variants(tag):
+    f = golden(f"forward_{tag}.npz")
+    ov = json.loads(str(f["overrides"]))
+    sd, dm, _, _ = oracle_model(seed=9, **ov)
+    out = O.score(sd, dm, T(f["init_pos"]), T(f["init_v"]), T(f["batch"]), T(f["shape"]), T(f["t"]))
+    for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+        assert maxabs(out[k], f[k]) < FWD_TOL, k
+
+
+def test_chain_b4_s50_torch_rng():
+    """BASELINE config 1 analogue: 4 molecules, 50 steps, the reference's own RNG draws replayed."""
+    sd, dm, _, _ = oracle_model()
+    c = golden("chain_b4_s50_torchrng.npz")
+    init_v = O.gumbel_argmax(torch.zeros(len(c["batch"]), 15), T(c["init_u"]))
+    assert np.array_equal(init_v.numpy(), c["init_v"])
+    r = O.sample_chain(sd, dm, T(c["init_pos"]), T(c["init_v"]), T(c["batch"]), T(c["shape"]), 50,
+                       lambda s: (c["eps"][s], c["u"][s]))
+    assert np.array_equal(r["v"].numpy(), c["v"])
+    assert np.array_equal(torch.stack(r["v_traj"]).numpy(), c["v_traj"])
+    assert maxabs(r["pos"], c["pos"]) < 1e-4
+    assert maxabs(torch.stack(r["pos_traj"]), c["pos_traj"]) < 1e-4
+    assert maxabs(r["v0_traj"][-1], c["v0_last"]) < 1e-4
+    assert maxabs(r["vt_traj"][-1], c["vt_last"]) < 1e-4
+    assert maxabs(r["pos_cond_traj"][-1], c["pos_cond_last"]) < 1e-4
+    assert maxabs(r["v_cond_traj"][-1], c["v_cond_last"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["b16_s100", "b4_s1000"])
+def test_chain_hash_noise(tag):
+    sd, dm, _, _ = oracle_model()
+    c = golden(f"chain_{tag}_hash.npz")
+    B, S, seed, every = int(c["B"]), int(c["S"]), int(c["seed"]), int(c["every"])
+    bb = synth.synthetic_batch(B, seed=seed)
+    n = len(bb["batch"])
+    r = O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S,
+                       lambda s: synth.step_noise(n, 15, s, seed=seed))
+    assert np.array_equal(r["v"].numpy(), c["v"])
+    assert np.array_equal(torch.stack(r["v_traj"][::every]).numpy(), c["v_traj_sub"])
+    assert maxabs(r["pos"], c["pos"]) < 1e-4
+    assert maxabs(torch.stack(r["pos_traj"][::every]), c["pos_traj_sub"]) < 1e-4
