@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: molecules/sec of 1000-step DDPM sampling at batch 256 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one reverse-diffusion step (one score evaluation + posterior update) of one batch of
+256 synthetic MOSES-sized molecules per GPU; value = molecules finished per second for 1000-step
+chains = (batch * n_gpus) / (1000 * seconds_per_step).  With the default K = 1000 the timed region
+IS one complete chain per GPU (plus, for N > 1, the RCCL gather of the generated molecules).
+Inputs are resident in HBM before the timed region; noise is generated on the device (Philox)
+inside it; per-step trajectories are written to HBM inside it (their D2H copy is reported
+separately as `traj_d2h_ms`, never part of `value`).
+
+Also on the JSON line: `roofline` of the dominant kernel (per-launch time from HIP events on the
+launch stream, measured live in a short eager pass after the timed region) and `cpu_baseline`
+(the CPU oracle timed on this host's cores on a bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import yaml  # noqa: E402
+from shapemol_amd import ScorePosNet3D, synth  # noqa: E402
+from shapemol_amd.dist import gather_molecules  # noqa: E402
+from shapemol_amd.runtime import ChainRunner  # noqa: E402
+
+TRAIN_YML = os.path.join(ROOT, "config", "training",
+                         "dgcnn_signeddist_512_attention_residue_uniform_pos0_10_pos1.e-7_0.01_6_v001.yml")
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+CHAIN_STEPS = 1000                 # the metric is quoted for 1000-step chains
+
+
+def executed_flops_per_atom_step(H, L, k, G=20, heads=16, C=15, S=32):
+    """FLOPs the kernels execute (factorised first layers), MAC = 2."""
+    edge_x2h = 2 * (G * H + H * H) * 2
+    edge_h2x = ((G * H + H * H) + (G * H + H * heads)) * 2
+    node = (4 * H * H + 2 * H * H) * 2 * 2 + (2 * H * H + H * H) * 2 + (1 + heads + 0) * heads * 3 * 2 * 2
+    per_layer = k * (edge_x2h + edge_h2x) + node
+    return L * per_layer + k * (G * H + H) * 2 + (H * H + H * C) * 2, edge_x2h
+
+
+def reference_flops_per_atom_step(k, L=8):
+    """reference formulation (full 308-wide first layers)."""
+    return L * (k * 417792 + 238784) + k * 5376 + 42496
+
+
+def cpu_baseline(cfg, batch, n_steps):
+    """The CPU oracle on the same workload, timed on this host (bounded sample)."""
+    from oracle import shapemol_oracle as O
+    # the box's CPU share is smaller than os.cpu_count(): oversubscribing OpenMP stalls the run
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), 16)))
+    sd = O.state_dict_from_numpy(synth.synthetic_state_dict(cfg, seed=7))
+    dm = O.Dims(cfg)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    n = len(batch["batch"])
+    args = (T(batch["init_pos"]), T(batch["init_v"]), T(batch["batch"]), T(batch["shape"]))
+    noise = lambda s: synth.step_noise(n, dm.C, s, seed=1)  # noqa: E731
+    O.sample_chain(sd, dm, *args, 1, noise, keep_traj=False)          # warm-up
+    t0 = time.perf_counter()
+    O.sample_chain(sd, dm, *args, n_steps, noise, keep_traj=True)
+    dt = (time.perf_counter() - t0) / n_steps
+    return dt, torch.get_num_threads()
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU (BASELINE config 2: 256)")
+    ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=6, help="reverse steps of the CPU oracle to time (0 = skip)")
+    ap.add_argument("--no-traj", action="store_true", help="do not keep per-step trajectories")
+    ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = yaml.safe_load(open(TRAIN_YML))["model"]
+    model = ScorePosNet3D(cfg, 15)
+    sdn = synth.synthetic_state_dict(cfg, seed=7)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+    model = model.to(dev)
+    steps, warm = min(args.steps, CHAIN_STEPS), max(0, min(args.warmup, CHAIN_STEPS))
+
+    bb = synth.synthetic_batch(args.batch, seed=2021 + rank)     # every rank owns a different batch
+    n_atoms = len(bb["batch"])
+    runner = ChainRunner(model, n_atoms, args.batch, max(steps, warm, 1), keep_traj=not args.no_traj, device=dev)
+    runner.load_batch(bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"])
+    counts = torch.from_numpy(bb["counts"]).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    use_graph = not args.eager
+    log(f"rank {rank}/{world}: {args.batch} molecules, {n_atoms} atoms; warmup {warm} steps")
+    if warm:
+        runner.run(warm, seed=11, use_graph=use_graph)
+        runner.synchronize()
+        if dist is not None:
+            gather_molecules(runner.out_pos, runner.out_v, counts)
+    barrier()
+    log(f"timing {steps} steps")
+    t0 = time.perf_counter()
+    runner.run(steps, seed=12, use_graph=use_graph)
+    runner.synchronize()
+    if dist is not None:
+        gather_molecules(runner.out_pos, runner.out_v, counts)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        natoms_all = torch.tensor([n_atoms], dtype=torch.int64, device=dev)
+        dist.all_reduce(natoms_all)
+        total_atoms = int(natoms_all.item())
+    else:
+        total_atoms = n_atoms
+    sec_per_step = elapsed / steps
+    value = args.batch * world / (CHAIN_STEPS * sec_per_step)
+
+    out = {
+        "metric": "molecules/sec (1000-step DDPM sample, batch 256)", "value": round(value, 3),
+        "unit": "molecules/s", "n_gpus": world, "steps": steps, "warmup": warm,
+        "ms_per_step": round(sec_per_step * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: batch 256 MOSES-prior molecules (9-27 atoms) per GPU, "
+                               "1000-step chain, fp32, k=8, synthetic shapes + hash-filled weights",
+                   "batch_per_gpu": args.batch, "atoms_per_gpu": n_atoms, "total_atoms": total_atoms,
+                   "noise": "device Philox", "trajectories": "kept in HBM" if not args.no_traj else "off",
+                   "launch": "hipGraph replay" if use_graph else "eager", "parallelism": f"dp{world} (whole batches per rank)"},
+    }
+
+    log(f"timed region done: {elapsed:.3f} s, {value:.2f} molecules/s")
+    if rank == 0:
+        # ---- roofline of the dominant kernel, from a short event-timed eager pass -------------
+        prof = runner.profile(max(1, args.profile_steps), seed=13)
+        runner.synchronize()
+        dm = model.dims
+        tot_ms = sum(v[0] for v in prof.values())
+        dom = max(prof, key=lambda k: prof[k][0])
+        dom_ms, dom_n = prof[dom]
+        avg_s = dom_ms * 1e-3 / dom_n
+        f_exec_total, f_edge_x2h = executed_flops_per_atom_step(dm.H, dm.L, dm.k, dm.G, dm.heads, dm.C, dm.S)
+        per_launch = {"edge_x2h": f_edge_x2h * dm.k * n_atoms,
+                      "edge_h2x": ((dm.G * dm.H + dm.H * dm.H) + (dm.G * dm.H + dm.H * dm.heads)) * 2 * dm.k * n_atoms}
+        flops = per_launch.get(dom, 0.0)
+        ach = flops / avg_s / 1e12 if flops else 0.0
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "flops_per_launch_executed": flops, "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_n,
+            "share_of_step": round(dom_ms / tot_ms, 3),
+            "step_tflops_executed": round(f_exec_total * n_atoms / sec_per_step / 1e12, 3),
+            "step_tflops_ref_equiv": round(reference_flops_per_atom_step(dm.k, dm.L) * n_atoms / sec_per_step / 1e12, 3),
+            "breakdown_ms_per_step": {k: round(v[0] / max(1, args.profile_steps), 4) for k, v in prof.items()},
+        }
+        log("profile pass done: " + ", ".join(f"{k}={v[0] / max(1, args.profile_steps):.3f}ms" for k, v in prof.items()))
+        # trajectory D2H cost (reported, never part of value)
+        if not args.no_traj:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _ = [runner.bufs[k][:steps].cpu() for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj")]
+            out["traj_d2h_ms"] = round((time.perf_counter() - t1) * 1e3, 2)
+        # ---- CPU baseline: the oracle on this host, bounded sample ---------------------------
+        if world == 1 and args.cpu_steps > 0:
+            log(f"CPU oracle baseline: {args.cpu_steps} steps")
+            dt, cores = cpu_baseline(cfg, bb, args.cpu_steps)
+            out["cpu_baseline"] = {"value": round(args.batch / (CHAIN_STEPS * dt), 4), "unit": "molecules/s", "cores": cores,
+                                   "kind": "port", "sample": f"{args.cpu_steps} reverse steps of the same B={args.batch} batch "
+                                   f"({dt:.3f} s/step, torch-CPU oracle), extrapolated to 1000 steps"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
