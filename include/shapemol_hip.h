@@ -108,7 +108,7 @@ int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, co
 
 /* ---- diagnostics (used by the parity tests and the bench; not needed by a caller) ---- */
 /* options: "stop_layer" (run only the first v layers of the next _score; -1 = all),
- *          "edge_waves" / "node_waves" (waves per workgroup, tuning). */
+ *          "edge_waves" (waves per workgroup of the edge kernels, tuning). */
 int shapemol_set_option(shapemol_ctx *ctx, const char *name, int64_t value);
 /* Copy an internal device buffer of the last _score to HOST memory (synchronises the device).
  * names: "nbr" (N,KP) i32, "ew" (N,KP) f32, "h" (N,H), "x" (N,3), "pre" (N,4H), "q" (N,H),

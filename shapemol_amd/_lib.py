@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshapemol_hip.so")
+LIB_PATH = os.path.join(_HERE, "libshapemol_hip_stamps.so" if os.environ.get("SHAPEMOL_STAMPS") == "1"
+                        else "libshapemol_hip.so")
 ABI_VERSION = 1
 
 EXPORTS = (

@@ -29,8 +29,7 @@ int fail(const std::string &m) { g_err = m; return 1; }
             return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
-constexpr int kEdgeThreadsDefault = 512;
-constexpr int kNodeThreadsDefault = 512;
+constexpr int kEdgeThreadsDefault = 768;
 
 // ---- host view of the packed weight array (order documented in shapemol_amd/packing.py) ----
 struct Lin { const float *w = nullptr, *b = nullptr; int out = 0, in = 0; };
@@ -109,12 +108,14 @@ struct Image {
     size_t put(const float *src, size_t n) { const size_t o = alloc(n); std::memcpy(&d[o], src, n * sizeof(float)); return o; }
 };
 
-struct DevMlp { size_t w1, b1, g, be, w2, b2; };
+struct DevMlp { size_t w1, b1, g, be, w2, b2; };            // raw row-major (VALU kernels)
+struct DevMlpImg { size_t w1img, b1, g, be, w2img, b2; int nt2; };   // MFMA A-fragment images (sm_node.h)
 struct DevLayer {
-    size_t pre_x2h, pre_h2x;          // [4H][H] concatenated first-layer node blocks (k_i, k_j, v_i, v_j)
+    size_t pre_x2h, pre_h2x;          // images of [4H][H]: first-layer node blocks (k_i, k_j, v_i, v_j)
+    size_t lin_img;                   // image of [8H][H]: pre_h2x of this layer followed by pre_x2h of the next
     size_t sk_x2h, sv_x2h, sk_h2x, sv_h2x;   // [H][SL] shape columns of the first layers
     size_t bk_x2h, bv_x2h, bk_h2x, bv_h2x;   // first-layer biases [H]
-    DevMlp q_x2h, q_h2x, no;
+    DevMlpImg q_x2h, q_h2x, no;
     size_t blob_x2h, blob_h2x;
     size_t vn_f, vn_d;                // original [heads][cin]
     size_t wf_x, wd_x, wf_o, wd_o, bn_g, bn_b;
@@ -123,9 +124,39 @@ struct DevModel {
     size_t tab[7];
     size_t te1w, te1b, te2w, te2b, embw, embb;
     DevMlp ew, inv;
-    size_t v1w, v1b, v2w, v2b;   // v2 padded to 16 rows
+    DevMlpImg vhead;             // Linear -> SSP -> Linear (second image padded to 16 rows)
     std::vector<DevLayer> layer;
 };
+
+// A-fragment image of W[rows][K] taken from src[r * ld + col0 + c]; rows padded with zeros to rows_pad
+size_t pack_image(Image &im, const float *src, int rows, int rows_pad, int K, int ld, int col0) {
+    const int ntk = K / 16;
+    const size_t o = im.alloc((size_t)rows_pad * K);
+    for (int t2 = 0; t2 < rows_pad / 16; ++t2)
+        for (int t = 0; t < ntk; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t2 + (lane & 15), col = 16 * t + 4 * (lane >> 4) + r;
+                    im.d[o + ((size_t)(t2 * ntk + t) * 64 + lane) * 4 + r] = row < rows ? src[(size_t)row * ld + col0 + col] : 0.f;
+                }
+    return o;
+}
+size_t put_padded(Image &im, const float *src, int n, int n_pad) {
+    const size_t o = im.alloc(n_pad);
+    std::memcpy(&im.d[o], src, n * sizeof(float));
+    return o;
+}
+DevMlpImg put_mlp_img(Image &im, const Mlp &m) {
+    DevMlpImg d;
+    const int r2 = (m.l2.out + 15) / 16 * 16;
+    d.w1img = pack_image(im, m.l1.w, m.l1.out, m.l1.out, m.l1.in, m.l1.in, 0);
+    d.b1 = im.put(m.l1.b, m.l1.out);
+    d.g = m.g ? im.put(m.g, m.l1.out) : 0; d.be = m.be ? im.put(m.be, m.l1.out) : 0;
+    d.w2img = pack_image(im, m.l2.w, m.l2.out, r2, m.l2.in, m.l2.in, 0);
+    d.b2 = put_padded(im, m.l2.b, m.l2.out, r2);
+    d.nt2 = r2 / 16;
+    return d;
+}
 
 int head_of_row(int m, int nt) {     // value row 4g + r of the h2x edge kernel -> head index, -1 = padding
     const int g = m >> 2, r = m & 3;
@@ -163,31 +194,26 @@ template <int H>
 void build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D) {
     const int G = c.num_r_gaussian, SL = c.shape_latent_dim, S = c.shape_dim, hd = c.n_heads;
     const int kv = G + 2 * H + SL, cin = 1 + hd + S, NT = H / 16;
-    auto put_pre = [&](const Mlp &k, const Mlp &v) {
-        const size_t o = im.alloc((size_t)4 * H * H);
+    auto put_pre = [&](const Mlp &k, const Mlp &v) {      // 4 images of [H][H]: k_i, k_j, v_i, v_j column blocks
         const Mlp *src[4] = {&k, &k, &v, &v};
-        for (int blk = 0; blk < 4; ++blk)
-            for (int f = 0; f < H; ++f)
-                std::memcpy(&im.d[o + ((size_t)blk * H + f) * H], src[blk]->l1.w + (size_t)f * kv + G + (blk & 1) * H, H * sizeof(float));
-        return o;
+        size_t first = 0;
+        for (int blk = 0; blk < 4; ++blk) {
+            const size_t o = pack_image(im, src[blk]->l1.w, H, H, H, kv, G + (blk & 1) * H);
+            if (blk == 0) first = o;
+            else if (o != first + (size_t)blk * H * H) std::abort();     // images must be contiguous
+        }
+        return first;
     };
     auto put_scols = [&](const Mlp &m) {
         const size_t o = im.alloc((size_t)H * SL);
         for (int f = 0; f < H; ++f) std::memcpy(&im.d[o + (size_t)f * SL], m.l1.w + (size_t)f * kv + G + 2 * H, SL * sizeof(float));
         return o;
     };
-    auto put_mlp = [&](const Mlp &m) {
-        DevMlp d;
-        d.w1 = im.put(m.l1.w, (size_t)m.l1.out * m.l1.in); d.b1 = im.put(m.l1.b, m.l1.out);
-        d.g = im.put(m.g, m.l1.out); d.be = im.put(m.be, m.l1.out);
-        d.w2 = im.put(m.l2.w, (size_t)m.l2.out * m.l2.in); d.b2 = im.put(m.l2.b, m.l2.out);
-        return d;
-    };
     D.pre_x2h = put_pre(L.hk, L.hv); D.pre_h2x = put_pre(L.xk, L.xv);
     D.sk_x2h = put_scols(L.hk); D.sv_x2h = put_scols(L.hv); D.sk_h2x = put_scols(L.xk); D.sv_h2x = put_scols(L.xv);
     D.bk_x2h = im.put(L.hk.l1.b, H); D.bv_x2h = im.put(L.hv.l1.b, H);
     D.bk_h2x = im.put(L.xk.l1.b, H); D.bv_h2x = im.put(L.xv.l1.b, H);
-    D.q_x2h = put_mlp(L.hq); D.q_h2x = put_mlp(L.xq); D.no = put_mlp(L.no);
+    D.q_x2h = put_mlp_img(im, L.hq); D.q_h2x = put_mlp_img(im, L.xq); D.no = put_mlp_img(im, L.no);
     {
         using B = EdgeBlob<H, false>;
         const size_t o = im.alloc(B::TOTAL); D.blob_x2h = o; float *b = &im.d[o];
@@ -228,16 +254,20 @@ struct shapemol_ctx {
     int64_t capN = 0, capB = 0;
     std::vector<void *> allocs;
     int *mol_of = nullptr, *mol_off = nullptr, *t_mol = nullptr, *nbr = nullptr, *steps = nullptr;
-    float *temb = nullptr, *inv = nullptr, *add = nullptr, *ps = nullptr, *ew = nullptr;
-    float *h_a = nullptr, *h_b = nullptr, *pre = nullptr, *q = nullptr, *att = nullptr, *o3 = nullptr, *pd = nullptr;
+    float *temb = nullptr, *inv = nullptr, *add0 = nullptr, *addp = nullptr, *ps = nullptr, *ew = nullptr;
+    float *h_a = nullptr, *h_b = nullptr, *pre0 = nullptr, *preAB = nullptr, *q_x = nullptr, *q_h = nullptr, *att = nullptr, *o3 = nullptr, *pd = nullptr;
     float *x_a = nullptr, *x_b = nullptr, *x_state = nullptr, *pred_pos = nullptr, *pred_v = nullptr;
     int64_t *v_state = nullptr;
+    unsigned long long *stamps = nullptr;   // [1024][2] diagnostic clock stamps
+    unsigned long long *kstamps = nullptr;  // per-wave phase stamps of ONE selected kernel launch (SM_STAMPS build)
+    int kstamp_sel = -1;                    // which launch: 0 node_pre, 1 edge_x2h, 2 edge_h2x (layer 0)
+    int stamp_on = 0;
     double *bn_acc = nullptr;
     // last evaluation (debug_read)
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, node_threads = kNodeThreadsDefault;
+    int stop_layer = -1, edge_threads = kEdgeThreadsDefault;
     int num_cu = 256;
     // profiling
     bool prof_on = false;
@@ -287,11 +317,11 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
     };
     if (A(&c->mol_of, capN) || A(&c->mol_off, capB + 1) || A(&c->t_mol, capB) || A(&c->nbr, capN * c->KP) ||
         A(&c->steps, 4) || A(&c->temb, capB * g.time_emb_dim) || A(&c->inv, capB * g.shape_latent_dim) ||
-        A(&c->add, (size_t)L * 2 * capB * 4 * H) || A(&c->ps, (size_t)L * capB * 2 * hd * 3) || A(&c->ew, capN * c->KP) ||
-        A(&c->h_a, capN * H) || A(&c->h_b, capN * H) || A(&c->pre, capN * 4 * H) || A(&c->q, capN * H) ||
+        A(&c->add0, (size_t)capB * 4 * H) || A(&c->addp, (size_t)L * capB * 8 * H) || A(&c->ps, (size_t)L * capB * 2 * hd * 3) || A(&c->ew, capN * c->KP) ||
+        A(&c->h_a, capN * H) || A(&c->h_b, capN * H) || A(&c->pre0, capN * 4 * H) || A(&c->preAB, capN * 8 * H) || A(&c->q_x, capN * H) || A(&c->q_h, capN * H) ||
         A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
         A(&c->x_b, capN * 3) || A(&c->x_state, capN * 3) || A(&c->pred_pos, capN * 3) ||
-        A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->bn_acc, (size_t)L * 2 * hd))
+        A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * 2 * hd))
         return 1;
     c->capN = capN; c->capB = capB;
     return 0;
@@ -303,8 +333,12 @@ int set_edge_attr(int KP) {
 #define SETATTR(K)                                                                                                    \
     HIPCHK(hipFuncSetAttribute((const void *)edge_attention_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b0)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_attention_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b1));
-    if (KP == 8) { SETATTR(8) } else if (KP == 16) { SETATTR(16) } else { SETATTR(32) }
+#define SETATTR1(K)                                                                                                   \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_attention_t1_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b0)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_attention_t1_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b1));
+    if (KP == 8) { SETATTR1(8) } else if (KP == 16) { SETATTR1(16) } else { SETATTR(32) }
 #undef SETATTR
+#undef SETATTR1
     return 0;
 }
 
@@ -316,19 +350,41 @@ int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {
     const int grid = std::max(1, std::min(c->num_cu, njobs));
     const size_t shm = EdgeBlob<H, H2X>::TOTAL * sizeof(float);
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
-    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 8, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
-    else if (KP == 16) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 16, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 8, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    else if (KP == 16) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 16, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
     else LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
     return 0;
 }
 
-NodeJob mlp_job(const shapemol_ctx *c, const DevMlp &m, const float *in0, const float *in1, int K, int H,
-                int mode, int n_out2, const float *resid, float *out, int ld_out, int n_store) {
-    NodeJob j{};
-    j.in0 = in0; j.in1 = in1; j.w1 = c->P(m.w1); j.b1 = c->P(m.b1); j.ldw1 = K; j.n_out1 = H; j.mode = mode;
-    j.ln_g = c->P(m.g); j.ln_b = c->P(m.be); j.w2 = c->P(m.w2); j.b2 = c->P(m.b2); j.n_out2 = n_out2;
-    j.resid = resid; j.out = out; j.ld_out = ld_out; j.n_store = n_store;
-    return j;
+template <int H, int KT>
+int launch_mlp2(shapemol_ctx *c, hipStream_t s, const char *name, const DevMlpImg &m, const float *in0, const float *in1,
+                int mode, const float *resid, float *out, int ld_out, int n_store, int n_atoms) {
+    NodeMlpArgs a{};
+    a.in0 = in0; a.in1 = in1; a.w1img = c->P(m.w1img); a.b1 = c->P(m.b1); a.ln_g = c->P(m.g); a.ln_b = c->P(m.be);
+    a.w2img = c->P(m.w2img); a.b2 = c->P(m.b2); a.resid = resid; a.out = out; a.ld_out = ld_out; a.n_store = n_store;
+    a.mode = mode; a.nt2 = m.nt2; a.n_atoms = n_atoms;
+    const int n_ct = (n_atoms + 15) / 16, teams = NodeMlpLds<H>::TEAMS;
+    LAUNCH(name, hipLaunchKernelGGL((node_mlp2_kernel<H, KT>), dim3((n_ct + teams - 1) / teams), dim3(kNodeThreads), 0, s, a));
+    return 0;
+}
+
+template <int H>
+int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float *in, const float *wimg, const float *add_mol,
+                  int ld_add, float *out, int ld_out, int n_out_tiles, int n_atoms, unsigned long long *stamps) {
+    const int n_ct = (n_atoms + 15) / 16, ogroups = (n_out_tiles + 15) / 16;
+    const int want_groups = std::max(1, c->num_cu / ogroups);
+    const int tpg = std::max(1, (n_ct + want_groups - 1) / want_groups);
+    const int agroups = (n_ct + tpg - 1) / tpg;
+    NodeLinArgs a{in, wimg, add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps};
+    LAUNCH(name, hipLaunchKernelGGL(node_linear_kernel<H>, dim3(ogroups * agroups), dim3(kNodeThreads), 0, s, a));
+    return 0;
+}
+
+NodeFollow follow_of(const shapemol_ctx *c, const DevMlpImg &m, int mode, float *out, int ld_out, int n_store) {
+    NodeFollow f{};
+    f.w1img = c->P(m.w1img); f.b1 = c->P(m.b1); f.ln_g = c->P(m.g); f.ln_b = c->P(m.be);
+    f.w2img = c->P(m.w2img); f.b2 = c->P(m.b2); f.out = out; f.ld_out = ld_out; f.n_store = n_store; f.mode = mode; f.nt2 = m.nt2;
+    return f;
 }
 
 // Step-invariant per-batch quantities (molecule index, invariant shape embedding, shape terms)
@@ -340,14 +396,22 @@ int run_prep(shapemol_ctx *c, hipStream_t s, const int64_t *d_batch, int64_t N, 
     ShapeInvArgs si{d_shape, c->P(c->dm.inv.w1), c->P(c->dm.inv.b1), c->P(c->dm.inv.g), c->P(c->dm.inv.be),
                     c->P(c->dm.inv.w2), c->P(c->dm.inv.b2), c->inv, S, SL};
     LAUNCH("prep", hipLaunchKernelGGL(shape_invariant_kernel, dim3(B), dim3(64), 0, s, si));
+    {   // layer-0 x2h term: [B][4H]
+        const DevLayer &D = c->dm.layer[0];
+        ShapeTermArgs st{c->inv, c->P(D.sk_x2h), c->P(D.bk_x2h), c->P(D.sv_x2h), c->P(D.bv_x2h), c->add0, SL, H, SL, 4 * H};
+        LAUNCH("prep", hipLaunchKernelGGL(shape_term_kernel, dim3(B), dim3(256), 0, s, st));
+    }
     for (int l = 0; l < L; ++l) {
         const DevLayer &D = c->dm.layer[l];
-        ShapeTermArgs st{c->inv, c->P(D.sk_x2h), c->P(D.bk_x2h), c->P(D.sv_x2h), c->P(D.bv_x2h),
-                         c->add + ((size_t)l * 2 + 0) * c->capB * 4 * H, SL, H, SL};
-        LAUNCH("prep", hipLaunchKernelGGL(shape_term_kernel, dim3(B), dim3(256), 0, s, st));
-        ShapeTermArgs st2{c->inv, c->P(D.sk_h2x), c->P(D.bk_h2x), c->P(D.sv_h2x), c->P(D.bv_h2x),
-                          c->add + ((size_t)l * 2 + 1) * c->capB * 4 * H, SL, H, SL};
+        // paired terms [B][8H]: this layer's h2x | the next layer's x2h (both products of the same new h)
+        float *addp = c->addp + (size_t)l * c->capB * 8 * H;
+        ShapeTermArgs st2{c->inv, c->P(D.sk_h2x), c->P(D.bk_h2x), c->P(D.sv_h2x), c->P(D.bv_h2x), addp, SL, H, SL, 8 * H};
         LAUNCH("prep", hipLaunchKernelGGL(shape_term_kernel, dim3(B), dim3(256), 0, s, st2));
+        if (l + 1 < L) {
+            const DevLayer &Dn = c->dm.layer[l + 1];
+            ShapeTermArgs st{c->inv, c->P(Dn.sk_x2h), c->P(Dn.bk_x2h), c->P(Dn.sv_x2h), c->P(Dn.bv_x2h), addp + 4 * H, SL, H, SL, 8 * H};
+            LAUNCH("prep", hipLaunchKernelGGL(shape_term_kernel, dim3(B), dim3(256), 0, s, st));
+        }
         VnShapeArgs vs{d_shape, c->P(D.vn_f), c->P(D.vn_d), c->ps + (size_t)l * c->capB * 2 * hd * 3, S, hd};
         LAUNCH("prep", hipLaunchKernelGGL(vn_shape_kernel, dim3(B), dim3(128), 0, s, vs));
     }
@@ -377,32 +441,43 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     const float *cur_x = x_in;
     float *cur_h = c->h_a;
     const int nlay = c->stop_layer >= 0 ? std::min(c->stop_layer, L) : L;
-    const dim3 ngrid2((N + 15) / 16, 2), ngrid1((N + 15) / 16, 1);
+    constexpr int NT = H / 16;
+    bool v_done = false;
+    if (nlay > 0) {   // prologue: per-node products and queries of the first x2h attention
+        const DevLayer &D0 = c->dm.layer[0];
+        if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(D0.pre_x2h), c->add0, 4 * H, c->pre0, 4 * H, 4 * NT, n,
+                             c->kstamp_sel == 0 ? c->kstamps : nullptr)) return 1;
+        if (launch_mlp2<H, 1>(c, s, "node_q", D0.q_x2h, cur_h, nullptr, NODE_LN_RELU, nullptr, c->q_x, H, H, n)) return 1;
+    }
     for (int l = 0; l < nlay; ++l) {
         const DevLayer &Dl = c->dm.layer[l];
-        const bool last = (l == nlay - 1);
-        for (int half = 0; half < 2; ++half) {   // 0: x2h, 1: h2x
-            if (half == 1) {
-                // node_output MLP on [att | h] + residual -> new h
-                float *dst = (last && out_h) ? out_h : (cur_h == c->h_a ? c->h_b : c->h_a);
-                NodeArgs na{};
-                na.job[0] = mlp_job(c, Dl.no, c->att, cur_h, 2 * H, H, NODE_LN_RELU, H, cur_h, dst, H, H);
-                na.mol_of = c->mol_of; na.n_atoms = n;
-                LAUNCH("node_out", hipLaunchKernelGGL(node_mlp_kernel<H>, ngrid1, dim3(c->node_threads), 0, s, na));
-                cur_h = dst;
-            }
-            // per-node halves of the edge MLPs' first Linear + the query MLP
-            NodeArgs na{};
-            NodeJob &j0 = na.job[0];
-            j0.in0 = cur_h; j0.w1 = c->P(half ? Dl.pre_h2x : Dl.pre_x2h); j0.ldw1 = H; j0.n_out1 = 4 * H;
-            j0.add_mol = c->add + ((size_t)l * 2 + half) * c->capB * 4 * H; j0.mode = NODE_LINEAR;
-            j0.out = c->pre; j0.ld_out = 4 * H; j0.n_store = 4 * H;
-            na.job[1] = mlp_job(c, half ? Dl.q_h2x : Dl.q_x2h, cur_h, nullptr, H, H, NODE_LN_RELU, H, nullptr, c->q, H, H);
-            na.mol_of = c->mol_of; na.n_atoms = n;
-            LAUNCH("node_pre", hipLaunchKernelGGL(node_mlp_kernel<H>, ngrid2, dim3(c->node_threads), 0, s, na));
-            EdgeArgs e{c->P(half ? Dl.blob_h2x : Dl.blob_x2h), c->pre, c->q, cur_x, c->nbr, c->ew, half ? c->o3 : c->att, n};
-            if (half == 0) { if (launch_edge<H, false>(c, s, e)) return 1; }
-            else           { if (launch_edge<H, true>(c, s, e)) return 1; }
+        const bool last = (l == nlay - 1), has_next = !last;
+        {   // x2h attention
+            EdgeArgs e{c->P(Dl.blob_x2h), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew, c->att, n,
+                       l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
+            if (launch_edge<H, false>(c, s, e)) return 1;
+        }
+        {   // node side: h' = h + MLP([att | h]); queries of h2x (this layer) and x2h (next layer) or the v head
+            float *dst = (last && out_h) ? out_h : (cur_h == c->h_a ? c->h_b : c->h_a);
+            NodeChainArgs na{};
+            na.att = c->att; na.h = cur_h; na.h_out = dst; na.n_atoms = n;
+            na.w1img = c->P(Dl.no.w1img); na.b1 = c->P(Dl.no.b1); na.ln_g = c->P(Dl.no.g); na.ln_b = c->P(Dl.no.be);
+            na.w2img = c->P(Dl.no.w2img); na.b2 = c->P(Dl.no.b2);
+            na.f[0] = follow_of(c, Dl.q_h2x, NODE_LN_RELU, c->q_h, H, H);
+            na.n_follow = 1;
+            if (has_next) { na.f[1] = follow_of(c, c->dm.layer[l + 1].q_x2h, NODE_LN_RELU, c->q_x, H, H); na.n_follow = 2; }
+            else if (out_v) { na.f[1] = follow_of(c, c->dm.vhead, NODE_SSP, out_v, C, C); na.n_follow = 2; v_done = true; }
+            const int n_ct = (n + 15) / 16, teams = NodeMlpLds<H>::TEAMS;
+            LAUNCH("node_chain", hipLaunchKernelGGL(node_chain_kernel<H>, dim3((n_ct + teams - 1) / teams), dim3(kNodeThreads), 0, s, na));
+            cur_h = dst;
+            // per-node halves of the edge MLPs' first Linear: h2x of this layer | x2h of the next one
+            if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
+                                 c->preAB, 8 * H, (has_next && l + 1 < L ? 8 : 4) * NT, n, nullptr)) return 1;
+        }
+        {   // h2x attention
+            EdgeArgs e{c->P(Dl.blob_h2x), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->o3, n, 8 * H,
+                       (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
+            if (launch_edge<H, true>(c, s, e)) return 1;
         }
         float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
         VnArgs va{cur_x, c->o3, c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o),
@@ -414,13 +489,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     }
     c->last_h = cur_h; c->last_x = cur_x;
     if (nlay == 0 && out_pos) HIPCHK(hipMemcpyAsync(out_pos, x_in, N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (out_v) {
-        NodeArgs na{};
-        NodeJob &j = na.job[0];
-        j.in0 = cur_h; j.w1 = c->P(c->dm.v1w); j.b1 = c->P(c->dm.v1b); j.ldw1 = H; j.n_out1 = H; j.mode = NODE_SSP;
-        j.w2 = c->P(c->dm.v2w); j.b2 = c->P(c->dm.v2b); j.n_out2 = C; j.out = out_v; j.ld_out = C; j.n_store = C;
-        na.mol_of = c->mol_of; na.n_atoms = n;
-        LAUNCH("v_head", hipLaunchKernelGGL(node_mlp_kernel<H>, ngrid1, dim3(c->node_threads), 0, s, na));
+    if (out_v && !v_done) {
+        if (launch_mlp2<H, 1>(c, s, "v_head", c->dm.vhead, cur_h, nullptr, NODE_SSP, nullptr, out_v, C, C, n)) return 1;
     }
     return 0;
 }
@@ -439,6 +509,7 @@ int run_ddpm(shapemol_ctx *c, hipStream_t s, int64_t N, const float *d_eps, cons
     if (tr) { a.tr_pos = tr->pos_traj; a.tr_v = tr->v_traj; a.tr_v0 = tr->v0_traj; a.tr_vt = tr->vt_traj;
               a.tr_pos_cond = tr->pos_cond_traj; a.tr_v_cond = tr->v_cond_traj; }
     a.n_atoms = (int)N; a.C = g.num_classes;
+    if (c->stamp_on) LAUNCH("stamp", hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(64), 0, s, c->stamps, c->steps + 1, 1024));
     LAUNCH("ddpm", hipLaunchKernelGGL(ddpm_step_kernel<32>, dim3((N + 127) / 128), dim3(128), 0, s, a));
     return 0;
 }
@@ -501,13 +572,21 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
     };
     dm.ew = put_mlp(hm.ew);
     dm.inv = put_mlp(hm.inv);
-    dm.v1w = im.put(hm.v1.w, (size_t)H * H); dm.v1b = im.put(hm.v1.b, H);
-    dm.v2w = im.alloc((size_t)((C + 15) / 16) * 16 * H); std::memcpy(&im.d[dm.v2w], hm.v2.w, (size_t)C * H * sizeof(float));
-    dm.v2b = im.alloc(((C + 15) / 16) * 16); std::memcpy(&im.d[dm.v2b], hm.v2.b, C * sizeof(float));
+    {
+        Mlp vh; vh.l1 = hm.v1; vh.l2 = hm.v2; vh.g = nullptr; vh.be = nullptr;
+        dm.vhead = put_mlp_img(im, vh);
+    }
     dm.layer.resize(cfg->num_layers);
     for (int l = 0; l < cfg->num_layers; ++l) {
         if (H == 128) build_layer_image<128>(*cfg, hm.layer[l], im, dm.layer[l]);
         else build_layer_image<32>(*cfg, hm.layer[l], im, dm.layer[l]);
+    }
+    for (int l = 0; l < cfg->num_layers; ++l) {      // paired images: pre_h2x(l) | pre_x2h(l + 1)
+        const size_t blk = (size_t)4 * H * H;
+        const size_t o = im.alloc(2 * blk);
+        std::memcpy(&im.d[o], &im.d[dm.layer[l].pre_h2x], blk * sizeof(float));
+        if (l + 1 < cfg->num_layers) std::memcpy(&im.d[o + blk], &im.d[dm.layer[l + 1].pre_x2h], blk * sizeof(float));
+        dm.layer[l].lin_img = o;
     }
     im.alloc(64);
     if (hipMalloc((void **)&c->d_img, im.d.size() * sizeof(float)) != hipSuccess) { delete c; return fail("hipMalloc(weights) failed"); }
@@ -609,8 +688,9 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail("shapemol_set_option: null argument");
     const std::string k(name);
     if (k == "stop_layer") c->stop_layer = (int)value;
-    else if (k == "edge_waves") { if (value < 1 || value > 8) return fail("edge_waves must be 1..8"); c->edge_threads = (int)value * 64; }
-    else if (k == "node_waves") { if (value < 1 || value > 8) return fail("node_waves must be 1..8"); c->node_threads = (int)value * 64; }
+    else if (k == "stamps") c->stamp_on = (int)value;
+    else if (k == "kstamp_sel") c->kstamp_sel = (int)value;
+    else if (k == "edge_waves") { if (value < 1 || value > 12) return fail("edge_waves must be 1..12"); c->edge_threads = (int)value * 64; }
     else return fail("unknown option " + k);
     if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
     return 0;
@@ -628,10 +708,12 @@ int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t
     else if (k == "ew") { src = c->ew; bytes = N * c->KP * 4; }
     else if (k == "h") { src = c->last_h; bytes = N * g.hidden_dim * 4; }
     else if (k == "x") { src = c->last_x; bytes = N * 3 * 4; }
-    else if (k == "pre") { src = c->pre; bytes = N * 4 * g.hidden_dim * 4; }
-    else if (k == "q") { src = c->q; bytes = N * g.hidden_dim * 4; }
+    else if (k == "pre") { src = c->preAB; bytes = N * 8 * g.hidden_dim * 4; }
+    else if (k == "q") { src = c->q_h; bytes = N * g.hidden_dim * 4; }
     else if (k == "att") { src = c->att; bytes = N * g.hidden_dim * 4; }
     else if (k == "o3") { src = c->o3; bytes = N * 48 * 4; }
+    else if (k == "stamps") { src = c->stamps; bytes = 2048 * 8; }
+    else if (k == "kstamps") { src = c->kstamps; bytes = (size_t)8 * 16 * 4096 * 8; }
     else if (k == "bnstat") { src = c->bn_acc; bytes = (size_t)g.num_layers * 2 * g.n_heads * 8; }
     else { fail("shapemol_debug_read: unknown buffer " + k); return -1; }
     if (!src || bytes > max_bytes) { fail("shapemol_debug_read: buffer unavailable or destination too small"); return -1; }

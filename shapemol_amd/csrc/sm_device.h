@@ -16,6 +16,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SM_DEV __device__ __forceinline__
 
+// Diagnostic phase stamps (only in the -DSM_STAMPS build, tools/ only): 100 MHz real-time counter,
+// taken after draining the wave's outstanding memory operations so that a stamp closes its phase.
+#ifdef SM_STAMPS
+#define SM_STAMP(buf, slot)                                                                        \
+    do {                                                                                           \
+        if ((buf) != nullptr && (threadIdx.x & 63) == 0) {                                         \
+            unsigned long long t_;                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            (buf)[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = t_; \
+        }                                                                                          \
+    } while (0)
+#else
+#define SM_STAMP(buf, slot) do { } while (0)
+#endif
+
 SM_DEV f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -23,12 +40,67 @@ SM_DEV f32x4 mfma16(float a, float b, f32x4 c) {
 SM_DEV float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 SM_DEV void stg4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
-// sum over the four lane groups (same n, g = 0..3)
-SM_DEV float sum_groups(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+// Cooperative global -> LDS copy of `n4` float4 by all `nthr` threads of the workgroup, eight
+// independent 16-byte loads in flight per thread (a plain copy loop is serialised on the L2 latency).
+SM_DEV void copy_to_lds(float *lds, const float *g, int n4, int tid, int nthr) {
+    const float4 *src = reinterpret_cast<const float4 *>(g);
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    constexpr int U = 8;
+    int i = tid;
+    for (; i + (U - 1) * nthr < n4; i += U * nthr) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * nthr];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[i + u * nthr] = v[u];
+    }
+    for (; i < n4; i += nthr) dst[i] = src[i];
+}
+
+// ---- cross-lane helpers without LDS traffic ------------------------------------------------------
+// DPP row operations (within a 16-lane row) and the gfx950 permlane swaps (between rows); a
+// __shfl_xor would lower to ds_bpermute_b32 (LDS pipe, ~100+ cycles of latency each).
+template <int CTRL>
+SM_DEV float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7 - i inside each 8-lane half row
+constexpr int DPP_ROW_MIRROR = 0x140;   // lane i <-> 15 - i inside each 16-lane row
+
+// all-reduce over the SEGW (8 or 16) consecutive lanes of a row segment
+template <int SEGW>
+SM_DEV float seg_sum(float v) {
+    v += dpp_mov<DPP_XOR1>(v);
+    v += dpp_mov<DPP_XOR2>(v);
+    v += dpp_mov<DPP_HALF_MIRROR>(v);
+    if constexpr (SEGW == 16) v += dpp_mov<DPP_ROW_MIRROR>(v);
     return v;
 }
+template <int SEGW>
+SM_DEV float seg_max(float v) {
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    if constexpr (SEGW == 16) v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return v;
+}
+// v(lane) + v(lane ^ 16): v_permlane16_swap exchanges the odd rows of its first operand with the even
+// rows of the second; with both operands = v the two results are {r0,r0,r2,r2} and {r1,r1,r3,r3}.
+// (inline asm: the builtin folds swap(v, v) to (v, v); the s_nop covers the VALU-write hazard.)
+SM_DEV float sum_xor16(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+SM_DEV float sum_xor32(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// sum over the four lane groups (same n, g = 0..3)
+SM_DEV float sum_groups(float v) { return sum_xor32(sum_xor16(v)); }
 
 // In-register LayerNorm (eps 1e-5, biased variance, two-pass) + ReLU of one D-layout column
 // vector; gamma/beta are read from `gb` ([H] gamma followed by [H] beta) at the lane's features.
@@ -60,15 +132,22 @@ SM_DEV void ln_relu_dlayout(float (&v)[NT * 4], const float *gamma, const float 
 // (LDS or global; one 16-byte read per lane feeds four k-steps).
 template <int NT, int NT2>
 SM_DEV void gemm_packed(const float *w, const float (&act)[NT * 4], f32x4 (&acc)[NT2], int lane) {
-#pragma unroll
+    constexpr int CH = NT2 < 4 ? NT2 : 4;       // output blocks in flight: CH independent accumulators
+#pragma unroll                                  // between two dependent MFMAs (dependent latency 40 cycles)
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int t2 = 0; t2 < NT2; ++t2) {
-            const float4 a = ldg4(w + ((t2 * NT + t) * 64 + lane) * 4);
-            acc[t2] = mfma16(a.x, act[4 * t + 0], acc[t2]);
-            acc[t2] = mfma16(a.y, act[4 * t + 1], acc[t2]);
-            acc[t2] = mfma16(a.z, act[4 * t + 2], acc[t2]);
-            acc[t2] = mfma16(a.w, act[4 * t + 3], acc[t2]);
+        for (int c0 = 0; c0 < NT2; c0 += CH) {
+            float4 a[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) a[i] = ldg4(w + (((c0 + i) * NT + t) * 64 + lane) * 4);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[c0 + i] = mfma16(a[i].x, act[4 * t + 0], acc[c0 + i]);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[c0 + i] = mfma16(a[i].y, act[4 * t + 1], acc[c0 + i]);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[c0 + i] = mfma16(a[i].z, act[4 * t + 2], acc[c0 + i]);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[c0 + i] = mfma16(a[i].w, act[4 * t + 3], acc[c0 + i]);
         }
     }
 }

@@ -28,6 +28,8 @@ struct EdgeArgs {
     const float *ew;        // [N][KP]  edge weight sigma(...)
     float *out;             // x2h: [N][H] attention output; h2x: [N][16][3] rows 4g+r (permuted heads)
     int n_atoms;
+    int ld_pre;             // row stride of `pre` in floats (4H, or 8H when two products share a buffer)
+    unsigned long long *stamps;   // diagnostic build only
 };
 
 // LDS image of one edge kernel's weights, in floats.
@@ -78,7 +80,7 @@ SM_DEV void edge_hidden(const float *a_row, const float *b_row, const float (&rb
 }
 
 template <int H, int KP, bool H2X>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(768)
 edge_attention_kernel(EdgeArgs a) {
     using BL = EdgeBlob<H, H2X>;
     constexpr int NT = BL::NT;
@@ -88,9 +90,10 @@ edge_attention_kernel(EdgeArgs a) {
     constexpr int SEGW = (KP >= 16) ? 16 : KP;      // lanes (columns) of one atom inside a tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    for (int i = threadIdx.x; i < BL::TOTAL / 4; i += blockDim.x)
-        reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(a.blob)[i];
+    SM_STAMP(a.stamps, 0);
+    copy_to_lds(lds, a.blob, BL::TOTAL / 4, threadIdx.x, blockDim.x);
     __syncthreads();
+    SM_STAMP(a.stamps, 1);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int n = lane & 15, g = lane >> 4;
@@ -102,7 +105,7 @@ edge_attention_kernel(EdgeArgs a) {
         const bool atom_ok = atom_raw < a.n_atoms;
         const int atom = atom_ok ? atom_raw : a.n_atoms - 1;
         const float xi0 = a.x[atom * 3 + 0], xi1 = a.x[atom * 3 + 1], xi2 = a.x[atom * 3 + 2];
-        const float *pre_i = a.pre + (size_t)atom * 4 * H;
+        const float *pre_i = a.pre + (size_t)atom * a.ld_pre;
 
         // ---- pass 1: keys and logits of every tile of the job --------------------------------
         float logit[TPJ][NT];
@@ -128,8 +131,9 @@ edge_attention_kernel(EdgeArgs a) {
             float rb[5];
             rbf_dlayout(d, g, rb);
             float hid[NT * 4];
-            edge_hidden<NT>(pre_i, a.pre + (size_t)j * 4 * H + H, rb, lds + BL::K_WR, lds + BL::K_G,
+            edge_hidden<NT>(pre_i, a.pre + (size_t)j * a.ld_pre + H, rb, lds + BL::K_WR, lds + BL::K_G,
                             lds + BL::K_B, lane, g, hid);
+            SM_STAMP(a.stamps, 2);
             f32x4 kacc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -137,12 +141,13 @@ edge_attention_kernel(EdgeArgs a) {
                 kacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
             }
             gemm_packed<NT, NT>(lds + BL::K_W2, hid, kacc, lane);
+            SM_STAMP(a.stamps, 3);
             // logit of head 2t + (g >> 1): 4 dims here + 4 dims in the partner lane group (g ^ 1)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float4 qq = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g);
                 float p = qq.x * kacc[t][0] + qq.y * kacc[t][1] + qq.z * kacc[t][2] + qq.w * kacc[t][3];
-                p += __shfl_xor(p, 16, 64);
+                p = sum_xor16(p);
                 p = ok ? p * inv_sqrt_dh : -INFINITY;
                 logit[tt][t] = p;
                 mx[t] = fmaxf(mx[t], p);
@@ -152,8 +157,7 @@ edge_attention_kernel(EdgeArgs a) {
         float den[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int m = 1; m < SEGW; m <<= 1) mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], m, 64));
+            mx[t] = seg_max<SEGW>(mx[t]);
             float s = 0.f;
 #pragma unroll
             for (int tt = 0; tt < TPJ; ++tt) {
@@ -161,11 +165,11 @@ edge_attention_kernel(EdgeArgs a) {
                 logit[tt][t] = e;
                 s += e;
             }
-#pragma unroll
-            for (int m = 1; m < SEGW; m <<= 1) s += __shfl_xor(s, m, 64);
+            s = seg_sum<SEGW>(s);
             den[t] = s > 0.f ? 1.0f / s : 0.f;
         }
 
+        SM_STAMP(a.stamps, 4);
         // ---- pass 2: values, weighted by alpha * e_w, summed over the slots ---------------------
         constexpr int NOUT = H2X ? 12 : NT * 4;
         float osum[NOUT];
@@ -181,7 +185,7 @@ edge_attention_kernel(EdgeArgs a) {
             float rb[5];
             rbf_dlayout(d, g, rb);
             float hid[NT * 4];
-            edge_hidden<NT>(pre_i + 2 * H, a.pre + (size_t)j * 4 * H + 3 * H, rb, lds + BL::V_WR,
+            edge_hidden<NT>(pre_i + 2 * H, a.pre + (size_t)j * a.ld_pre + 3 * H, rb, lds + BL::V_WR,
                             lds + BL::V_G, lds + BL::V_B, lane, g, hid);
             f32x4 vacc[NT2V];
 #pragma unroll
@@ -189,7 +193,9 @@ edge_attention_kernel(EdgeArgs a) {
                 const float4 b2 = ldg4(lds + BL::V_B2 + 16 * t + 4 * g);
                 vacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
             }
+            SM_STAMP(a.stamps, 5);
             gemm_packed<NT, NT2V>(lds + BL::V_W2, hid, vacc, lane);
+            SM_STAMP(a.stamps, 6);
             const float w = ok ? a.ew[atom * KP + slot] : 0.f;
             if constexpr (!H2X) {
 #pragma unroll
@@ -217,10 +223,7 @@ edge_attention_kernel(EdgeArgs a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < NOUT; ++i) {
-#pragma unroll
-            for (int m = 1; m < SEGW; m <<= 1) osum[i] += __shfl_xor(osum[i], m, 64);
-        }
+        for (int i = 0; i < NOUT; ++i) osum[i] = seg_sum<SEGW>(osum[i]);
         if (atom_ok && (n % SEGW) == 0) {
             if constexpr (!H2X) {
                 float *o = a.out + (size_t)atom * H;
@@ -234,5 +237,184 @@ edge_attention_kernel(EdgeArgs a) {
                     stg4(o + 4 * i, float4{osum[4 * i], osum[4 * i + 1], osum[4 * i + 2], osum[4 * i + 3]});
             }
         }
+        SM_STAMP(a.stamps, 7);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Single-tile variant (KP <= 16: all neighbour slots of an atom sit in one 16-column tile).
+// With ~2.8k jobs and ~3k wave slots every wave runs one job, so the kernel time IS the latency of
+// one job; this version shortens that critical path: the job's index / coordinate / gather / query
+// loads are issued BEFORE the 154 KB weight image is copied to LDS (their L2 latency hides under the
+// copy), the value-path gathers are issued before the softmax of the key path, and all reductions
+// are DPP / permlane operations.
+// -------------------------------------------------------------------------------------------------
+template <int NT>
+SM_DEV void hidden_from_regs(const float4 (&ga)[NT], const float4 (&gb)[NT], const float (&rb)[5], const float *wr,
+                             const float *gamma, const float *beta, int lane, int g, float (&hid)[NT * 4]) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(wr[(t * 5 + s) * 64 + lane], rb[s], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
+        hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
+    }
+    ln_relu_dlayout<NT>(hid, gamma, beta, g);
+}
+
+template <int H, int KP, bool H2X>
+__global__ void __launch_bounds__(768)
+edge_attention_t1_kernel(EdgeArgs a) {
+    static_assert(KP == 8 || KP == 16, "single-tile variant");
+    using BL = EdgeBlob<H, H2X>;
+    constexpr int NT = BL::NT;
+    constexpr int NT2V = BL::NT2V;
+    constexpr int APJ = 16 / KP;
+    constexpr int SEGW = KP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int njobs = (a.n_atoms + APJ - 1) / APJ;
+    const int jstride = gridDim.x * nwave;
+    const float inv_sqrt_dh = 0.35355339059327373f;   // 1/sqrt(8)
+
+    int job = blockIdx.x + gridDim.x * wave;
+    bool have = job < njobs;
+    // per-job state loaded ahead of use
+    int atom = 0, jn = 0;
+    bool atom_ok = false, ok = false;
+    float xi[3], xj[3], ewv = 0.f;
+    float4 ga[NT], gb[NT], qv[NT];
+
+    auto issue_loads = [&](int jb) {
+        const int atom_raw = jb * APJ + n / SEGW;
+        atom_ok = atom_raw < a.n_atoms;
+        atom = atom_ok ? atom_raw : a.n_atoms - 1;
+        const int slot = n % SEGW;
+        const int jraw = a.nbr[atom * KP + slot];
+        ok = atom_ok && jraw >= 0;
+        jn = ok ? jraw : atom;
+        ewv = a.ew[atom * KP + slot];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { xi[k] = a.x[atom * 3 + k]; xj[k] = a.x[jn * 3 + k]; }
+        const float *pi = a.pre + (size_t)atom * a.ld_pre, *pj = a.pre + (size_t)jn * a.ld_pre + H;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            ga[t] = ldg4(pi + 16 * t + 4 * g);
+            gb[t] = ldg4(pj + 16 * t + 4 * g);
+        }
+    };
+    SM_STAMP(a.stamps, 0);
+    if (have) issue_loads(job);
+    copy_to_lds(lds, a.blob, BL::TOTAL / 4, threadIdx.x, blockDim.x);
+    __syncthreads();
+    SM_STAMP(a.stamps, 1);
+
+    while (have) {
+        // keep the loop-invariant LDS weight reads inside the loop (see edge_attention_kernel)
+        asm volatile("" ::: "memory");
+        float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
+        const float d = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
+        float rb[5];
+        rbf_dlayout(d, g, rb);
+        float alpha[NT];
+        {
+            float hid[NT * 4];
+            hidden_from_regs<NT>(ga, gb, rb, lds + BL::K_WR, lds + BL::K_G, lds + BL::K_B, lane, g, hid);
+            SM_STAMP(a.stamps, 2);
+            // query row: its latency hides under the second Linear
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qv[t] = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g);
+            f32x4 kacc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 b2 = ldg4(lds + BL::K_B2 + 16 * t + 4 * g);
+                kacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
+            }
+            gemm_packed<NT, NT>(lds + BL::K_W2, hid, kacc, lane);
+            SM_STAMP(a.stamps, 3);
+            // value-path neighbour gather: issued now, consumed after the softmax
+            const float *pj = a.pre + (size_t)jn * a.ld_pre + 3 * H;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) gb[t] = ldg4(pj + 16 * t + 4 * g);
+            // logit of head 2t + (g >> 1): 4 dims here + 4 dims in the partner lane group (g ^ 1)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float p = qv[t].x * kacc[t][0] + qv[t].y * kacc[t][1] + qv[t].z * kacc[t][2] + qv[t].w * kacc[t][3];
+                p = sum_xor16(p);
+                p = ok ? p * inv_sqrt_dh : -INFINITY;
+                const float mx = seg_max<SEGW>(p);
+                const float e = ok ? expf(p - mx) : 0.f;
+                const float s = seg_sum<SEGW>(e);
+                alpha[t] = s > 0.f ? e / s : 0.f;
+            }
+        }
+        SM_STAMP(a.stamps, 4);
+        const float w = ok ? ewv : 0.f;
+        {
+            const float *pi = a.pre + (size_t)atom * a.ld_pre + 2 * H;      // centre row: shared by the atom's lanes
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ga[t] = ldg4(pi + 16 * t + 4 * g);
+            float hid[NT * 4];
+            hidden_from_regs<NT>(ga, gb, rb, lds + BL::V_WR, lds + BL::V_G, lds + BL::V_B, lane, g, hid);
+            SM_STAMP(a.stamps, 5);
+            f32x4 vacc[NT2V];
+#pragma unroll
+            for (int t = 0; t < NT2V; ++t) {
+                const float4 b2 = ldg4(lds + BL::V_B2 + 16 * t + 4 * g);
+                vacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
+            }
+            gemm_packed<NT, NT2V>(lds + BL::V_W2, hid, vacc, lane);
+            SM_STAMP(a.stamps, 6);
+            const int out_atom = atom;
+            const bool out_ok = atom_ok && (n % SEGW) == 0;
+            job += jstride;
+            have = job < njobs;
+            float relk[3] = {rel[0], rel[1], rel[2]};
+            if constexpr (!H2X) {
+                float o[NT * 4];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float aw = alpha[t] * w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[4 * t + r] = seg_sum<SEGW>(aw * vacc[t][r]);
+                }
+                if (out_ok) {
+                    float *op = a.out + (size_t)out_atom * H;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        stg4(op + 16 * t + 4 * g, float4{o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]});
+                }
+                if (have) issue_loads(job);
+            } else {
+                // value row 4g + r belongs to head 2*((NT/2)*(g&1) + r) + (g>>1), whose alpha this lane
+                // holds in alpha[(NT/2)*(g&1) + r]; rows with r >= NT/2 are zero padding.
+                float o[12];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float al = 0.f;
+                    if (r < NT / 2) al = (g & 1) ? alpha[(NT / 2 + r) % NT] : alpha[r];
+                    const float av = al * w * vacc[0][r];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) o[3 * r + k] = seg_sum<SEGW>(av * relk[k]);
+                }
+                if (out_ok) {
+                    float *op = a.out + (size_t)out_atom * 48 + 12 * g;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        stg4(op + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
+                }
+                if (have) issue_loads(job);
+            }
+        }
+        SM_STAMP(a.stamps, 7);
     }
 }

@@ -77,8 +77,8 @@ struct ShapeTermArgs {
     const float *inv;      // [B][SL]
     const float *wk, *bk;  // W1 of the k MLP [H][ldw] (pointer already at column G+2H), bias [H]
     const float *wv, *bv;
-    float *add;            // [B][4H]
-    int ldw, H, SL;
+    float *add;            // [B][ld] (4H columns written)
+    int ldw, H, SL, ld;
 };
 __global__ void shape_term_kernel(ShapeTermArgs a) {
     const int b = blockIdx.x;
@@ -90,7 +90,7 @@ __global__ void shape_term_kernel(ShapeTermArgs a) {
             v = (blk == 0 ? a.bk : a.bv)[ff];
             for (int i = 0; i < a.SL; ++i) v += w[i] * a.inv[(size_t)b * a.SL + i];
         }
-        a.add[(size_t)b * 4 * a.H + f] = v;
+        a.add[(size_t)b * a.ld + f] = v;
     }
 }
 
@@ -489,4 +489,13 @@ __global__ void copy_state_kernel(const float *x_src, const int64_t *v_src, floa
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_atoms * 3 && x_dst) x_dst[i] = x_src[i];
     if (i < n_atoms && v_dst) v_dst[i] = v_src[i];
+}
+
+// diagnostic: shader-clock / real-time stamp pairs (clock = d(memtime) / d(memrealtime) * 100 MHz)
+__global__ void clock_stamp_kernel(unsigned long long *out, const int *step_cur, int cap) {
+    const int i = step_cur ? *step_cur : 0;
+    if (threadIdx.x == 0 && i < cap) {
+        out[2 * i] = __builtin_amdgcn_s_memtime();
+        out[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 }

@@ -1,4 +1,4 @@
-// Node kernels: every per-atom Linear / MLP of the score network as one generic MFMA kernel.
+// Node kernels: every per-atom Linear / MLP of the score network on fp32 MFMA.
 //
 // Reference semantics (paths relative to the reference repository):
 //   MLP = Linear -> LayerNorm -> ReLU -> Linear          models/common.py:47-67
@@ -7,114 +7,170 @@
 //   v_inference = Linear -> ShiftedSoftplus -> Linear    models/molopt_score_model.py:262-266,305
 //   the per-node halves W_i h_i, W_j h_j of the edge MLPs' first Linear (see sm_edge.h)
 //
-// One workgroup owns 16 atoms (one D-layout tile, sm_device.h); its waves split the OUTPUT
-// features (16-row weight blocks) between them and stream their weight rows straight from
-// global memory/L2 as the MFMA A operand (row-major [out][in], one 16-byte load = 4 k-steps),
-// while the 16 x K activation tile is the B operand held in registers by every wave.
-// A two-layer job exchanges the hidden tile through LDS so each wave sees all H hidden features.
+// Weights are pre-packed on the host into MFMA A-fragment images
+//     img[((t2 * NTK + t) * 64 + lane) * 4 + r] = W[16*t2 + (lane & 15)][16*t + 4*(lane >> 4) + r]
+// (NTK = K / 16).  Both kernels are WEIGHT-STATIONARY IN REGISTERS: a wave owns one 16-row block of
+// output features, reads its A fragments once (8 KB, perfectly coalesced) and keeps them in VGPRs
+// while 16-atom column tiles stream through as the B operand in the D layout (sm_device.h).
+// With only ~5.5k atoms per batch the problem is latency- and balance-bound, not FLOP-bound:
+// no LDS weight copy, no barrier in the linear kernel, grids sized to the CU count.
+//
+//   node_linear_kernel : out[N][OT*16] = in[N][H] W^T (+ per-molecule term).  16 waves = 16 output
+//                        blocks per workgroup; the workgroup walks the column tiles of its atom group.
+//   node_mlp2_kernel   : Linear(K->H) -> LN+ReLU | SSP -> Linear(H->R2) [+ residual] for 16/NT column
+//                        tiles per workgroup; the NT waves of a team split the hidden features and
+//                        exchange the hidden tile through LDS once (LayerNorm needs all of them).
 #pragma once
 #include "sm_device.h"
 
-enum NodeMode { NODE_LINEAR = 0, NODE_LN_RELU = 1, NODE_SSP = 2 };
+enum NodeMode { NODE_LN_RELU = 1, NODE_SSP = 2 };
+constexpr int kNodeThreads = 1024;
 
-struct NodeJob {
-    const float *in0;     // [N][H]
-    const float *in1;     // [N][H] second half of the input (K = 2H) or nullptr (K = H)
-    const float *w1;      // [n_out1][ldw1] row-major, n_out1 % 16 == 0
-    const float *add_mol; // per-molecule additive term [B][n_out1] (bias folded in) or nullptr
-    const float *b1;      // [n_out1] or nullptr
-    const float *ln_g;    // NODE_LN_RELU
-    const float *ln_b;
-    const float *w2;      // [n_out2 padded to 16][H] row-major
-    const float *b2;      // [n_out2 padded to 16]
-    const float *resid;   // [N][H] added to the output, or nullptr
-    float *out;           // [N][ld_out]
-    int ldw1, n_out1, mode, n_out2, ld_out, n_store;
-};
-
-struct NodeArgs {
-    NodeJob job[2];       // blockIdx.y selects
-    const int *mol_of;    // [N]
-    int n_atoms;
+struct NodeLinArgs {
+    const float *in;        // [N][H]
+    const float *wimg;      // packed image of [OT*16][H]
+    const float *add_mol;   // per-molecule additive term [B][OT*16] (bias folded in) or nullptr
+    const int *mol_of;      // [N]
+    float *out;             // [N][OT*16]
+    int n_atoms, n_out_tiles, tiles_per_group;
+    int ld_add, ld_out;           // row strides of add_mol and out (floats)
+    unsigned long long *stamps;   // diagnostic build only
 };
 
 template <int H>
-__global__ void __launch_bounds__(512)
-node_mlp_kernel(NodeArgs args) {
+__global__ void __launch_bounds__(kNodeThreads)
+node_linear_kernel(NodeLinArgs a) {
     constexpr int NT = H / 16;
-    constexpr int XS = H + 16;                        // LDS row stride of the exchange tile
-    __shared__ __attribute__((aligned(16))) float xch[16 * XS];
-    const NodeJob &J = args.job[blockIdx.y];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int atom_raw = blockIdx.x * 16 + n;
-    const bool atom_ok = atom_raw < args.n_atoms;
-    const int atom = atom_ok ? atom_raw : args.n_atoms - 1;
-    const bool two = J.in1 != nullptr;
+    const int ogroups = (a.n_out_tiles + 15) / 16;
+    const int ot = (blockIdx.x % ogroups) * 16 + wave;
+    const int ag = blockIdx.x / ogroups;
+    if (ot >= a.n_out_tiles) return;
+    const int n_ct = (a.n_atoms + 15) / 16;
+    const int ct0 = ag * a.tiles_per_group, ct1 = min(ct0 + a.tiles_per_group, n_ct);
+    if (ct0 >= ct1) return;
+    SM_STAMP(a.stamps, 0);
 
-    // B operand: the 16 x K input tile in D layout (k-step 4t + r <- register 4t + r)
-    float bin[2 * NT * 4];
+    float4 w[NT];                                                   // this wave's weight block, resident
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float4 v = ldg4(J.in0 + (size_t)atom * H + 16 * t + 4 * g);
-        bin[4 * t] = v.x; bin[4 * t + 1] = v.y; bin[4 * t + 2] = v.z; bin[4 * t + 3] = v.w;
+    for (int t = 0; t < NT; ++t) w[t] = ldg4(a.wimg + ((size_t)(ot * NT + t) * 64 + lane) * 4);
+
+    float4 cur[NT], nxt[NT];
+    {
+        const int atom = min(ct0 * 16 + n, a.n_atoms - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cur[t] = ldg4(a.in + (size_t)atom * H + 16 * t + 4 * g);
     }
-    if (two) {
+    SM_STAMP(a.stamps, 1);
+    for (int ct = ct0; ct < ct1; ++ct) {
+        if (ct + 1 < ct1) {
+            const int atom_n = min((ct + 1) * 16 + n, a.n_atoms - 1);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 v = ldg4(J.in1 + (size_t)atom * H + 16 * t + 4 * g);
-            bin[4 * (NT + t)] = v.x; bin[4 * (NT + t) + 1] = v.y; bin[4 * (NT + t) + 2] = v.z; bin[4 * (NT + t) + 3] = v.w;
+            for (int t = 0; t < NT; ++t) nxt[t] = ldg4(a.in + (size_t)atom_n * H + 16 * t + 4 * g);
         }
-    }
-    const int mol = J.add_mol ? args.mol_of[atom] : 0;
-    const int nt1 = J.n_out1 / 16;
-
-    for (int t1 = wave; t1 < nt1; t1 += nwave) {
+        const int atom_raw = ct * 16 + n;
+        const bool atom_ok = atom_raw < a.n_atoms;
+        const int atom = atom_ok ? atom_raw : a.n_atoms - 1;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (J.add_mol) {
-            const float4 s = ldg4(J.add_mol + (size_t)mol * J.n_out1 + 16 * t1 + 4 * g);
+        if (a.add_mol) {
+            const float4 s = ldg4(a.add_mol + (size_t)a.mol_of[atom] * a.ld_add + 16 * ot + 4 * g);
             acc = f32x4{s.x, s.y, s.z, s.w};
         }
-        if (J.b1) {
-            const float4 s = ldg4(J.b1 + 16 * t1 + 4 * g);
-            acc += f32x4{s.x, s.y, s.z, s.w};
-        }
-        const float *wrow = J.w1 + (size_t)(16 * t1 + n) * J.ldw1 + 4 * g;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float4 w = ldg4(wrow + 16 * t);
-            acc = mfma16(w.x, bin[4 * t + 0], acc);
-            acc = mfma16(w.y, bin[4 * t + 1], acc);
-            acc = mfma16(w.z, bin[4 * t + 2], acc);
-            acc = mfma16(w.w, bin[4 * t + 3], acc);
+            acc = mfma16(w[t].x, cur[t].x, acc);
+            acc = mfma16(w[t].y, cur[t].y, acc);
+            acc = mfma16(w[t].z, cur[t].z, acc);
+            acc = mfma16(w[t].w, cur[t].w, acc);
         }
-        if (two) {
+        SM_STAMP(a.stamps, 2 + 2 * (ct - ct0 < 2 ? ct - ct0 : 2));
+        if (atom_ok) stg4(a.out + (size_t)atom * a.ld_out + 16 * ot + 4 * g, float4{acc[0], acc[1], acc[2], acc[3]});
+        SM_STAMP(a.stamps, 3 + 2 * (ct - ct0 < 2 ? ct - ct0 : 2));
 #pragma unroll
-            for (int t = NT; t < 2 * NT; ++t) {
-                const float4 w = ldg4(wrow + 16 * t);
-                acc = mfma16(w.x, bin[4 * t + 0], acc);
-                acc = mfma16(w.y, bin[4 * t + 1], acc);
-                acc = mfma16(w.z, bin[4 * t + 2], acc);
-                acc = mfma16(w.w, bin[4 * t + 3], acc);
+        for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
+    }
+}
+
+struct NodeMlpArgs {
+    const float *in0;      // [N][H]
+    const float *in1;      // [N][H] second half of the input when K = 2H, else unused
+    const float *w1img;    // packed image of [H][K]
+    const float *b1;       // [H]
+    const float *ln_g, *ln_b;
+    const float *w2img;    // packed image of [16*nt2][H]
+    const float *b2;       // [16*nt2]
+    const float *resid;    // [N][H] added to the output, or nullptr
+    float *out;            // [N][ld_out]
+    int ld_out, n_store, mode, nt2, n_atoms;
+};
+
+template <int H>
+struct NodeMlpLds {
+    static constexpr int NT = H / 16;
+    static constexpr int TEAMS = (16 / NT) < 4 ? (16 / NT) : 4;   // column tiles per workgroup (LDS budget)
+    static constexpr int XS = H + 16;                    // row stride of the exchange tile
+    static constexpr int TOTAL = TEAMS * 16 * XS;        // floats
+};
+
+template <int H, int KT>
+__global__ void __launch_bounds__(kNodeThreads)
+node_mlp2_kernel(NodeMlpArgs a) {
+    constexpr int NT = H / 16;
+    using L = NodeMlpLds<H>;
+    __shared__ __attribute__((aligned(16))) float xch[L::TOTAL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    // waves beyond TEAMS * NT (only when NT < 4) mirror an existing team: identical values, stores disabled
+    const int team = (wave / NT) % L::TEAMS, ot = wave % NT;
+    const bool mirror = (wave / NT) >= L::TEAMS;
+    const int ct = blockIdx.x * L::TEAMS + team;
+    const bool tile_ok = ct * 16 < a.n_atoms;
+    const int atom_raw = ct * 16 + n;
+    const bool atom_ok = atom_raw < a.n_atoms && !mirror;
+    const int atom = atom_raw < a.n_atoms ? atom_raw : a.n_atoms - 1;
+    float *xrow = xch + (team * 16 + n) * L::XS;
+
+    // ---- first Linear: this wave's 16 hidden features, K in phases of H ------------------------
+    {
+        const float4 b = ldg4(a.b1 + 16 * ot + 4 * g);
+        f32x4 acc = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int kp = 0; kp < KT; ++kp) {
+            const float *src = kp == 0 ? a.in0 : a.in1;
+            float4 w[NT], x[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w[t] = ldg4(a.w1img + ((size_t)(ot * KT * NT + kp * NT + t) * 64 + lane) * 4);
+                x[t] = ldg4(src + (size_t)atom * H + 16 * t + 4 * g);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc = mfma16(w[t].x, x[t].x, acc);
+                acc = mfma16(w[t].y, x[t].y, acc);
+                acc = mfma16(w[t].z, x[t].z, acc);
+                acc = mfma16(w[t].w, x[t].w, acc);
             }
         }
-        if (J.mode == NODE_LINEAR) {
-            if (atom_ok) stg4(J.out + (size_t)atom * J.ld_out + 16 * t1 + 4 * g, float4{acc[0], acc[1], acc[2], acc[3]});
-        } else {
-            stg4(xch + n * XS + 16 * t1 + 4 * g, float4{acc[0], acc[1], acc[2], acc[3]});
-        }
+        stg4(xrow + 16 * ot + 4 * g, float4{acc[0], acc[1], acc[2], acc[3]});
     }
-    if (J.mode == NODE_LINEAR) return;
+    // second-layer weights: issue the loads before the barrier so their latency overlaps it
+    const bool has2 = ot < a.nt2;
+    float4 w2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        w2[t] = has2 ? ldg4(a.w2img + ((size_t)(ot * NT + t) * 64 + lane) * 4) : float4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    if (!tile_ok || !has2) return;
 
     float hid[NT * 4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float4 v = ldg4(xch + n * XS + 16 * t + 4 * g);
+        const float4 v = ldg4(xrow + 16 * t + 4 * g);
         hid[4 * t] = v.x; hid[4 * t + 1] = v.y; hid[4 * t + 2] = v.z; hid[4 * t + 3] = v.w;
     }
-    if (J.mode == NODE_LN_RELU) {
-        ln_relu_dlayout<NT>(hid, J.ln_g, J.ln_b, g);
+    if (a.mode == NODE_LN_RELU) {
+        ln_relu_dlayout<NT>(hid, a.ln_g, a.ln_b, g);
     } else {   // ShiftedSoftplus: softplus(x) - ln 2   (models/common.py:39-45; torch threshold 20)
 #pragma unroll
         for (int i = 0; i < NT * 4; ++i) {
@@ -122,31 +178,172 @@ node_mlp_kernel(NodeArgs args) {
             hid[i] = (v > 20.f ? v : log1pf(expf(v))) - 0.6931471805599453f;
         }
     }
-    const int nt2 = (J.n_out2 + 15) / 16;
-    for (int t2 = wave; t2 < nt2; t2 += nwave) {
-        const float4 bb = ldg4(J.b2 + 16 * t2 + 4 * g);
-        f32x4 acc = {bb.x, bb.y, bb.z, bb.w};
-        const float *wrow = J.w2 + (size_t)(16 * t2 + n) * H + 4 * g;
+    const float4 bb = ldg4(a.b2 + 16 * ot + 4 * g);
+    f32x4 acc2 = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc2 = mfma16(w2[t].x, hid[4 * t + 0], acc2);
+        acc2 = mfma16(w2[t].y, hid[4 * t + 1], acc2);
+        acc2 = mfma16(w2[t].z, hid[4 * t + 2], acc2);
+        acc2 = mfma16(w2[t].w, hid[4 * t + 3], acc2);
+    }
+    if (!atom_ok) return;
+    const int f0 = 16 * ot + 4 * g;
+    if (a.resid) {
+        const float4 rr = ldg4(a.resid + (size_t)atom * H + f0);
+        acc2 += f32x4{rr.x, rr.y, rr.z, rr.w};
+    }
+    if (f0 + 4 <= a.n_store && (a.ld_out & 3) == 0) {
+        stg4(a.out + (size_t)atom * a.ld_out + f0, float4{acc2[0], acc2[1], acc2[2], acc2[3]});
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (f0 + k < a.n_store) a.out[(size_t)atom * a.ld_out + f0 + k] = acc2[k];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// node_chain_kernel: everything that follows the x2h attention of a layer on the node side, in one launch:
+//     h' = h + MLP_out([att | h])                                  (uni_transformer.py:82-88)
+//     up to two follow-up MLPs on h':  the query MLP of this layer's h2x attention, and either the
+//     query MLP of the NEXT layer's x2h attention (h does not change in h2x) or, on the last layer,
+//     the atom-type head v_inference.
+// A team of NT waves owns one 16-atom column tile and splits the feature blocks; the hidden tiles and
+// h' cross LDS (three buffers, three barriers in total).
+// -------------------------------------------------------------------------------------------------
+struct NodeFollow {
+    const float *w1img, *b1, *ln_g, *ln_b, *w2img, *b2;
+    float *out;
+    int ld_out, n_store, mode, nt2;
+};
+struct NodeChainArgs {
+    const float *att, *h;                                 // [N][H] each
+    const float *w1img, *b1, *ln_g, *ln_b, *w2img, *b2;   // node_output MLP (K = 2H)
+    float *h_out;                                         // [N][H]
+    NodeFollow f[2];
+    int n_follow, n_atoms;
+};
+
+template <int H>
+__global__ void __launch_bounds__(kNodeThreads)
+node_chain_kernel(NodeChainArgs a) {
+    constexpr int NT = H / 16;
+    using L = NodeMlpLds<H>;
+    __shared__ __attribute__((aligned(16))) float bufA[L::TOTAL], bufB[L::TOTAL], bufC[L::TOTAL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int team = (wave / NT) % L::TEAMS, ot = wave % NT;
+    const bool mirror = (wave / NT) >= L::TEAMS;
+    const int ct = blockIdx.x * L::TEAMS + team;
+    const int atom_raw = ct * 16 + n;
+    const bool atom_ok = atom_raw < a.n_atoms && !mirror;
+    const int atom = atom_raw < a.n_atoms ? atom_raw : a.n_atoms - 1;
+    const int row = (team * 16 + n) * L::XS;
+    const int f0 = 16 * ot + 4 * g;
+
+    auto gemm_rows = [&](const float *wimg, int ntk, int kt0, const float4 (&x)[NT], f32x4 acc) {
+        float4 w[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = ldg4(wimg + ((size_t)(ot * ntk + kt0 + t) * 64 + lane) * 4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float4 w = ldg4(wrow + 16 * t);
-            acc = mfma16(w.x, hid[4 * t + 0], acc);
-            acc = mfma16(w.y, hid[4 * t + 1], acc);
-            acc = mfma16(w.z, hid[4 * t + 2], acc);
-            acc = mfma16(w.w, hid[4 * t + 3], acc);
+            acc = mfma16(w[t].x, x[t].x, acc);
+            acc = mfma16(w[t].y, x[t].y, acc);
+            acc = mfma16(w[t].z, x[t].z, acc);
+            acc = mfma16(w[t].w, x[t].w, acc);
         }
+        return acc;
+    };
+    auto read_row = [&](const float *buf, float (&v)[NT * 4]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 q = ldg4(buf + row + 16 * t + 4 * g);
+            v[4 * t] = q.x; v[4 * t + 1] = q.y; v[4 * t + 2] = q.z; v[4 * t + 3] = q.w;
+        }
+    };
+    auto activate = [&](float (&v)[NT * 4], int mode, const float *gam, const float *bet) {
+        if (mode == NODE_LN_RELU) {
+            ln_relu_dlayout<NT>(v, gam, bet, g);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT * 4; ++i) v[i] = (v[i] > 20.f ? v[i] : log1pf(expf(v[i]))) - 0.6931471805599453f;
+        }
+    };
+    auto gemm_hid = [&](const float *wimg, const float (&v)[NT * 4], f32x4 acc) {
+        float4 w[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = ldg4(wimg + ((size_t)(ot * NT + t) * 64 + lane) * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc = mfma16(w[t].x, v[4 * t + 0], acc);
+            acc = mfma16(w[t].y, v[4 * t + 1], acc);
+            acc = mfma16(w[t].z, v[4 * t + 2], acc);
+            acc = mfma16(w[t].w, v[4 * t + 3], acc);
+        }
+        return acc;
+    };
+
+    // ---- stage 1: node_output MLP -------------------------------------------------------------
+    float4 hres;
+    {
+        float4 x[NT];
+        const float4 b = ldg4(a.b1 + f0);
+        f32x4 acc = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] = ldg4(a.att + (size_t)atom * H + 16 * t + 4 * g);
+        acc = gemm_rows(a.w1img, 2 * NT, 0, x, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] = ldg4(a.h + (size_t)atom * H + 16 * t + 4 * g);
+        hres = ldg4(a.h + (size_t)atom * H + f0);                // residual: this wave's 4 features of h
+        acc = gemm_rows(a.w1img, 2 * NT, NT, x, acc);
+        stg4(bufA + row + f0, float4{acc[0], acc[1], acc[2], acc[3]});
+    }
+    __syncthreads();
+    {
+        float hid[NT * 4];
+        read_row(bufA, hid);
+        activate(hid, NODE_LN_RELU, a.ln_g, a.ln_b);
+        const float4 b = ldg4(a.b2 + f0);
+        f32x4 acc = gemm_hid(a.w2img, hid, f32x4{b.x, b.y, b.z, b.w});
+        const float4 hn = {acc[0] + hres.x, acc[1] + hres.y, acc[2] + hres.z, acc[3] + hres.w};
+        stg4(bufB + row + f0, hn);
+        if (atom_ok) stg4(a.h_out + (size_t)atom * H + f0, hn);
+    }
+    __syncthreads();
+    if (a.n_follow == 0) return;
+
+    // ---- stage 2: follow-up MLPs on the new h ------------------------------------------------------
+    {
+        float4 x[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] = ldg4(bufB + row + 16 * t + 4 * g);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k < a.n_follow) {
+                const float4 b = ldg4(a.f[k].b1 + f0);
+                const f32x4 acc = gemm_rows(a.f[k].w1img, NT, 0, x, f32x4{b.x, b.y, b.z, b.w});
+                stg4((k == 0 ? bufA : bufC) + row + f0, float4{acc[0], acc[1], acc[2], acc[3]});
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k >= a.n_follow) break;
+        const NodeFollow &F = a.f[k];
+        if (ot >= F.nt2) continue;
+        float hid[NT * 4];
+        read_row(k == 0 ? bufA : bufC, hid);
+        activate(hid, F.mode, F.ln_g, F.ln_b);
+        const float4 b = ldg4(F.b2 + f0);
+        const f32x4 acc = gemm_hid(F.w2img, hid, f32x4{b.x, b.y, b.z, b.w});
         if (!atom_ok) continue;
-        const int f0 = 16 * t2 + 4 * g;
-        if (J.resid) {
-            const float4 r = ldg4(J.resid + (size_t)atom * H + f0);
-            acc += f32x4{r.x, r.y, r.z, r.w};
-        }
-        if (f0 + 4 <= J.n_store && (J.ld_out & 3) == 0) {
-            stg4(J.out + (size_t)atom * J.ld_out + f0, float4{acc[0], acc[1], acc[2], acc[3]});
+        if (f0 + 4 <= F.n_store && (F.ld_out & 3) == 0) {
+            stg4(F.out + (size_t)atom * F.ld_out + f0, float4{acc[0], acc[1], acc[2], acc[3]});
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (f0 + r < J.n_store) J.out[(size_t)atom * J.ld_out + f0 + r] = acc[r];
+                if (f0 + r < F.n_store) F.out[(size_t)atom * F.ld_out + f0 + r] = acc[r];
         }
     }
 }

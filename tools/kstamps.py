@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Developer tool: in-kernel phase timeline of one launch (needs the --stamps build).
+    SHAPEMOL_STAMPS=1 python tools/kstamps.py --sel 1     # 0 node_pre, 1 edge_x2h, 2 edge_h2x"""
+import argparse, os, sys
+os.environ["SHAPEMOL_STAMPS"] = "1"
+import numpy as np, torch, yaml
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from shapemol_amd import ScorePosNet3D, synth
+ap = argparse.ArgumentParser(); ap.add_argument("--sel", type=int, default=1); ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--waves", type=int, default=8)
+a = ap.parse_args()
+cfg = yaml.safe_load(open(os.path.join(ROOT, "config/training/dgcnn_signeddist_512_attention_residue_uniform_pos0_10_pos1.e-7_0.01_6_v001.yml")))["model"]
+m = ScorePosNet3D(cfg, 15); m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(cfg, 7).items()}); m = m.to("cuda:0")
+bb = synth.synthetic_batch(a.batch, seed=2021)
+T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+args = (T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(np.full(a.batch, 500, np.int64)))
+m(*args); m.set_option("edge_waves", a.waves)
+for _ in range(3): m(*args)
+torch.cuda.synchronize()
+m.set_option("kstamp_sel", a.sel)
+m(*args); torch.cuda.synchronize()
+st = m.debug_read("kstamps", (4096 * 16, 8), np.uint64).astype(np.int64)
+st = st[st[:, 0] > 0]
+t0 = st[:, 0].min()
+print(f"waves stamped: {len(st)}; all times in us relative to the earliest stamp 0")
+names = {0: ["start", "weights+tile0 loaded", "tile0 mfma", "tile0 stored", "tile1 mfma", "tile1 stored", "tile2 mfma", "tile2 stored"],
+         1: ["start", "weights in LDS", "k hidden (gather+GEMM1+LN)", "k GEMM2", "logits+softmax", "v hidden", "v GEMM2", "reduce+store (job 1)"]}
+nm = names[0 if a.sel == 0 else 1]
+for k in range(8):
+    col = st[:, k]; col = col[col > 0]
+    if len(col) == 0: continue
+    rel = (col - t0) / 100.0
+    print(f"  stamp {k} {nm[k]:32s} min {rel.min():7.2f}  median {np.median(rel):7.2f}  max {rel.max():7.2f}")
+d = np.diff(st, axis=1) / 100.0
+print("  median phase lengths (us):", " ".join(f"{np.median(d[:, k][st[:, k + 1] > 0]):.2f}" if (st[:, k + 1] > 0).any() else "-" for k in range(7)))
