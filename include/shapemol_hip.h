@@ -112,7 +112,7 @@ int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, co
 int shapemol_set_option(shapemol_ctx *ctx, const char *name, int64_t value);
 /* Copy an internal device buffer of the last _score to HOST memory (synchronises the device).
  * names: "nbr" (N,KP) i32, "ew" (N,KP) f32, "h" (N,H), "x" (N,3), "pre" (N,4H), "q" (N,H),
- *        "att" (N,H), "o3" (N,heads*3), "bnstat" (L,2,heads) f64, "dims" (8,) i64.
+ *        "att" (N,H), "o3" (N,48), "bnstat" (L,16,2,heads) f64, "dims" (8,) i64.
  * Returns the number of bytes written, or -1. */
 int64_t shapemol_debug_read(shapemol_ctx *ctx, const char *name, void *host_dst, size_t max_bytes);
 /* Per-kernel launch-time accounting with HIP events on the launch stream (bench only).

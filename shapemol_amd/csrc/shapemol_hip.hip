@@ -249,6 +249,7 @@ struct shapemol_ctx {
     int device = 0;
     int KP = 8;
     float *d_img = nullptr;
+    float *ttab = nullptr;      // [T][D] time-embedding table (built once)
     DevModel dm;
     // workspace
     int64_t capN = 0, capB = 0;
@@ -267,7 +268,7 @@ struct shapemol_ctx {
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = kEdgeThreadsDefault;
+    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 8;
     int num_cu = 256;
     // profiling
     bool prof_on = false;
@@ -321,7 +322,7 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
         A(&c->h_a, capN * H) || A(&c->h_b, capN * H) || A(&c->pre0, capN * 4 * H) || A(&c->preAB, capN * 8 * H) || A(&c->q_x, capN * H) || A(&c->q_h, capN * H) ||
         A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
         A(&c->x_b, capN * 3) || A(&c->x_state, capN * 3) || A(&c->pred_pos, capN * 3) ||
-        A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * 2 * hd))
+        A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * kBnReplicas * 2 * hd))
         return 1;
     c->capN = capN; c->capB = capB;
     return 0;
@@ -347,7 +348,9 @@ int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {
     const int KP = c->KP;
     const int apj = KP >= 16 ? 1 : 16 / KP;
     const int njobs = (a.n_atoms + apj - 1) / apj;
-    const int grid = std::max(1, std::min(c->num_cu, njobs));
+    const int waves = c->edge_threads / 64;
+    const int grid = KP <= 16 ? std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves))
+                              : std::max(1, std::min(c->num_cu, njobs));
     const size_t shm = EdgeBlob<H, H2X>::TOTAL * sizeof(float);
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
     if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 8, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
@@ -371,12 +374,13 @@ int launch_mlp2(shapemol_ctx *c, hipStream_t s, const char *name, const DevMlpIm
 template <int H>
 int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float *in, const float *wimg, const float *add_mol,
                   int ld_add, float *out, int ld_out, int n_out_tiles, int n_atoms, unsigned long long *stamps) {
-    const int n_ct = (n_atoms + 15) / 16, ogroups = (n_out_tiles + 15) / 16;
+    const int nwave = c->lin_waves;
+    const int n_ct = (n_atoms + 15) / 16, ogroups = (n_out_tiles + nwave - 1) / nwave;
     const int want_groups = std::max(1, c->num_cu / ogroups);
     const int tpg = std::max(1, (n_ct + want_groups - 1) / want_groups);
     const int agroups = (n_ct + tpg - 1) / tpg;
     NodeLinArgs a{in, wimg, add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps};
-    LAUNCH(name, hipLaunchKernelGGL(node_linear_kernel<H>, dim3(ogroups * agroups), dim3(kNodeThreads), 0, s, a));
+    LAUNCH(name, hipLaunchKernelGGL(node_linear_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), 0, s, a));
     return 0;
 }
 
@@ -425,11 +429,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     const shapemol_config &g = c->cfg;
     const int L = g.num_layers, hd = g.n_heads, C = g.num_classes, D = g.time_emb_dim, KP = c->KP;
     const int n = (int)N;
-    TimeEmbArgs te{c->P(c->dm.te1w), c->P(c->dm.te1b), c->P(c->dm.te2w), c->P(c->dm.te2b),
-                   sampling ? c->steps : nullptr, c->steps + 1, c->t_mol, c->temb, c->bn_acc, L * 2 * hd,
-                   (int)B, D, g.num_timesteps, t_first};
-    LAUNCH("embed", hipLaunchKernelGGL(time_embed_kernel, dim3((std::max<int64_t>(B, L * 2 * hd) + 63) / 64), dim3(64), 0, s, te));
-    AtomEmbArgs ae{c->P(c->dm.embw), c->P(c->dm.embb), v_in, c->mol_of, c->temb, c->h_a, n, H, C, D};
+    AtomEmbArgs ae{c->P(c->dm.embw), c->P(c->dm.embb), v_in, c->mol_of, c->ttab, c->t_mol, sampling ? c->steps : nullptr,
+                   c->steps + 1, c->bn_acc, c->h_a, n, H, C, D, t_first, L * kBnReplicas * 2 * hd};
     LAUNCH("embed", hipLaunchKernelGGL(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
     LAUNCH("knn", hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x_in, c->mol_of, c->mol_off, n, g.knn, KP, c->nbr));
     EdgeWeightArgs ea{x_in, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
@@ -481,9 +482,9 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         }
         float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
         VnArgs va{cur_x, c->o3, c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o),
-                  c->P(Dl.wd_o), c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * 2 * hd, x_next, n, hd};
+                  c->P(Dl.wd_o), c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, x_next, n, hd};
         const int per_blk = 256 / hd;
-        LAUNCH("vn_stats", hipLaunchKernelGGL(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
+        LAUNCH("vn_stats", hipLaunchKernelGGL(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(kVnThreads), 0, s, va));
         LAUNCH("vn_apply", hipLaunchKernelGGL(vn_apply_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
         cur_x = x_next;
     }
@@ -501,7 +502,7 @@ int run_ddpm(shapemol_ctx *c, hipStream_t s, int64_t N, const float *d_eps, cons
     const shapemol_config &g = c->cfg;
     DdpmArgs a{};
     a.pred_pos = c->pred_pos; a.pred_v = c->pred_v; a.x_t = c->x_state; a.v_t = c->v_state; a.mol_of = c->mol_of;
-    a.t_mol = c->t_mol;
+    a.t_first = c->cfg.num_timesteps - 1;
     a.c0 = c->P(c->dm.tab[0]); a.ct = c->P(c->dm.tab[1]); a.logvar = c->P(c->dm.tab[2]); a.log_a = c->P(c->dm.tab[3]);
     a.log_1ma = c->P(c->dm.tab[4]); a.log_abar = c->P(c->dm.tab[5]); a.log_1mabar = c->P(c->dm.tab[6]);
     a.eps = d_eps; a.u = d_u; a.step_cur = c->steps + 1; a.step_ptr = c->steps; a.seed = seed;
@@ -510,7 +511,8 @@ int run_ddpm(shapemol_ctx *c, hipStream_t s, int64_t N, const float *d_eps, cons
               a.tr_pos_cond = tr->pos_cond_traj; a.tr_v_cond = tr->v_cond_traj; }
     a.n_atoms = (int)N; a.C = g.num_classes;
     if (c->stamp_on) LAUNCH("stamp", hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(64), 0, s, c->stamps, c->steps + 1, 1024));
-    LAUNCH("ddpm", hipLaunchKernelGGL(ddpm_step_kernel<32>, dim3((N + 127) / 128), dim3(128), 0, s, a));
+    if (g.num_classes <= 16) LAUNCH("ddpm", hipLaunchKernelGGL(ddpm_step16_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, s, a));
+    else LAUNCH("ddpm", hipLaunchKernelGGL(ddpm_step_kernel<32>, dim3((N + 127) / 128), dim3(128), 0, s, a));
     return 0;
 }
 
@@ -592,6 +594,12 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
     if (hipMalloc((void **)&c->d_img, im.d.size() * sizeof(float)) != hipSuccess) { delete c; return fail("hipMalloc(weights) failed"); }
     if (hipMemcpy(c->d_img, im.d.data(), im.d.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { hipFree(c->d_img); delete c; return fail("hipMemcpy(weights) failed"); }
     if (H == 128 ? set_edge_attr<128>(c->KP) : set_edge_attr<32>(c->KP)) { hipFree(c->d_img); delete c; return 1; }
+    {   // time-embedding table over all timesteps
+        if (hipMalloc((void **)&c->ttab, (size_t)T * cfg->time_emb_dim * sizeof(float)) != hipSuccess) { hipFree(c->d_img); delete c; return fail("hipMalloc(time table) failed"); }
+        TimeTableArgs ta{c->P(dm.te1w), c->P(dm.te1b), c->P(dm.te2w), c->P(dm.te2b), c->ttab, T, cfg->time_emb_dim};
+        hipLaunchKernelGGL(time_table_kernel, dim3((T + 63) / 64), dim3(64), 0, nullptr, ta);
+        if (hipDeviceSynchronize() != hipSuccess) { hipFree(c->ttab); hipFree(c->d_img); delete c; return fail("time table kernel failed"); }
+    }
     *out = c;
     return 0;
 }
@@ -603,6 +611,7 @@ void shapemol_destroy(shapemol_ctx *c) {
     if (c->gexec) hipGraphExecDestroy(c->gexec);
     for (auto &r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (void *p : c->allocs) hipFree(p);
+    hipFree(c->ttab);
     hipFree(c->d_img);
     delete c;
 }
@@ -688,6 +697,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail("shapemol_set_option: null argument");
     const std::string k(name);
     if (k == "stop_layer") c->stop_layer = (int)value;
+    else if (k == "lin_waves") { if (value < 1 || value > 16) return fail("lin_waves must be 1..16"); c->lin_waves = (int)value; }
     else if (k == "stamps") c->stamp_on = (int)value;
     else if (k == "kstamp_sel") c->kstamp_sel = (int)value;
     else if (k == "edge_waves") { if (value < 1 || value > 12) return fail("edge_waves must be 1..12"); c->edge_threads = (int)value * 64; }
@@ -714,7 +724,7 @@ int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t
     else if (k == "o3") { src = c->o3; bytes = N * 48 * 4; }
     else if (k == "stamps") { src = c->stamps; bytes = 2048 * 8; }
     else if (k == "kstamps") { src = c->kstamps; bytes = (size_t)8 * 16 * 4096 * 8; }
-    else if (k == "bnstat") { src = c->bn_acc; bytes = (size_t)g.num_layers * 2 * g.n_heads * 8; }
+    else if (k == "bnstat") { src = c->bn_acc; bytes = (size_t)g.num_layers * kBnReplicas * 2 * g.n_heads * 8; }
     else { fail("shapemol_debug_read: unknown buffer " + k); return -1; }
     if (!src || bytes > max_bytes) { fail("shapemol_debug_read: buffer unavailable or destination too small"); return -1; }
     if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||

@@ -29,8 +29,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
             (buf)[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = t_; \
         }                                                                                          \
     } while (0)
+// same without draining memory operations: when the wave's instruction stream reaches this point
+#define SM_TICK(buf, slot)                                                                         \
+    do {                                                                                           \
+        if ((buf) != nullptr && (threadIdx.x & 63) == 0) {                                         \
+            unsigned long long t_;                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            (buf)[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = t_; \
+        }                                                                                          \
+    } while (0)
 #else
 #define SM_STAMP(buf, slot) do { } while (0)
+#define SM_TICK(buf, slot) do { } while (0)
 #endif
 
 SM_DEV f32x4 mfma16(float a, float b, f32x4 c) {

@@ -286,7 +286,9 @@ edge_attention_t1_kernel(EdgeArgs a) {
     const int jstride = gridDim.x * nwave;
     const float inv_sqrt_dh = 0.35355339059327373f;   // 1/sqrt(8)
 
-    int job = blockIdx.x + gridDim.x * wave;
+    // consecutive jobs per workgroup: its waves then work on the atoms of one or two molecules and the
+    // neighbour rows they gather (each row is wanted by ~k different edges) are shared through the CU's L1
+    int job = blockIdx.x * nwave + wave;
     bool have = job < njobs;
     // per-job state loaded ahead of use
     int atom = 0, jn = 0;
@@ -312,16 +314,16 @@ edge_attention_t1_kernel(EdgeArgs a) {
             gb[t] = ldg4(pj + 16 * t + 4 * g);
         }
     };
-    SM_STAMP(a.stamps, 0);
+    SM_TICK(a.stamps, 0);
     if (have) issue_loads(job);
     copy_to_lds(lds, a.blob, BL::TOTAL / 4, threadIdx.x, blockDim.x);
     __syncthreads();
-    SM_STAMP(a.stamps, 1);
+    SM_TICK(a.stamps, 1);
 
     while (have) {
         // keep the loop-invariant LDS weight reads inside the loop (see edge_attention_kernel)
         asm volatile("" ::: "memory");
-        float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
+        const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         const float d = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
         float rb[5];
         rbf_dlayout(d, g, rb);
@@ -329,7 +331,7 @@ edge_attention_t1_kernel(EdgeArgs a) {
         {
             float hid[NT * 4];
             hidden_from_regs<NT>(ga, gb, rb, lds + BL::K_WR, lds + BL::K_G, lds + BL::K_B, lane, g, hid);
-            SM_STAMP(a.stamps, 2);
+            SM_TICK(a.stamps, 2);
             // query row: its latency hides under the second Linear
 #pragma unroll
             for (int t = 0; t < NT; ++t) qv[t] = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g);
@@ -340,7 +342,7 @@ edge_attention_t1_kernel(EdgeArgs a) {
                 kacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
             }
             gemm_packed<NT, NT>(lds + BL::K_W2, hid, kacc, lane);
-            SM_STAMP(a.stamps, 3);
+            SM_TICK(a.stamps, 3);
             // value-path neighbour gather: issued now, consumed after the softmax
             const float *pj = a.pre + (size_t)jn * a.ld_pre + 3 * H;
 #pragma unroll
@@ -357,7 +359,7 @@ edge_attention_t1_kernel(EdgeArgs a) {
                 alpha[t] = s > 0.f ? e / s : 0.f;
             }
         }
-        SM_STAMP(a.stamps, 4);
+        SM_TICK(a.stamps, 4);
         const float w = ok ? ewv : 0.f;
         {
             const float *pi = a.pre + (size_t)atom * a.ld_pre + 2 * H;      // centre row: shared by the atom's lanes
@@ -365,7 +367,7 @@ edge_attention_t1_kernel(EdgeArgs a) {
             for (int t = 0; t < NT; ++t) ga[t] = ldg4(pi + 16 * t + 4 * g);
             float hid[NT * 4];
             hidden_from_regs<NT>(ga, gb, rb, lds + BL::V_WR, lds + BL::V_G, lds + BL::V_B, lane, g, hid);
-            SM_STAMP(a.stamps, 5);
+            SM_TICK(a.stamps, 5);
             f32x4 vacc[NT2V];
 #pragma unroll
             for (int t = 0; t < NT2V; ++t) {
@@ -373,12 +375,11 @@ edge_attention_t1_kernel(EdgeArgs a) {
                 vacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
             }
             gemm_packed<NT, NT2V>(lds + BL::V_W2, hid, vacc, lane);
-            SM_STAMP(a.stamps, 6);
+            SM_TICK(a.stamps, 6);
             const int out_atom = atom;
             const bool out_ok = atom_ok && (n % SEGW) == 0;
             job += jstride;
             have = job < njobs;
-            float relk[3] = {rel[0], rel[1], rel[2]};
             if constexpr (!H2X) {
                 float o[NT * 4];
 #pragma unroll
@@ -400,11 +401,16 @@ edge_attention_t1_kernel(EdgeArgs a) {
                 float o[12];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float al = 0.f;
-                    if (r < NT / 2) al = (g & 1) ? alpha[(NT / 2 + r) % NT] : alpha[r];
-                    const float av = al * w * vacc[0][r];
+                    // both candidates are formed and one is selected, so that `alpha` stays in registers
+                    // (a select between two array elements is turned into a dynamically indexed stack array)
+                    float av = 0.f;
+                    if (r < NT / 2) {
+                        const float av_lo = alpha[r] * w * vacc[0][r];
+                        const float av_hi = alpha[(NT / 2 + r) % NT] * w * vacc[0][r];
+                        av = (g & 1) ? av_hi : av_lo;
+                    }
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) o[3 * r + k] = seg_sum<SEGW>(av * relk[k]);
+                    for (int k = 0; k < 3; ++k) o[3 * r + k] = seg_sum<SEGW>(av * rel[k]);
                 }
                 if (out_ok) {
                     float *op = a.out + (size_t)out_atom * 48 + 12 * g;
@@ -415,6 +421,6 @@ edge_attention_t1_kernel(EdgeArgs a) {
                 if (have) issue_loads(job);
             }
         }
-        SM_STAMP(a.stamps, 7);
+        SM_TICK(a.stamps, 7);
     }
 }

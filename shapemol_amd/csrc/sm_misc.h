@@ -114,26 +114,17 @@ __global__ void vn_shape_kernel(VnShapeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// time embedding (molopt_score_model.py:154-166,247-252) + per-step bookkeeping
+// time embedding (molopt_score_model.py:154-166,247-252).  It depends on the timestep only, so the
+// table over all T timesteps is built once per context; a score evaluation just indexes it.
 // ---------------------------------------------------------------------------------------------
-struct TimeEmbArgs {
+struct TimeTableArgs {
     const float *w1, *b1, *w2, *b2;  // Linear D->2D, Linear 2D->D
-    const int *step_ptr;             // sampling: device step counter (t = t_first-step); nullptr: use t_mol
-    int *step_cur;                   // stable copy of the counter for the rest of this step's kernels
-    int *t_mol;                      // [B]
-    float *temb;                     // [B][D]
-    double *bn_acc;                  // zeroed here at the start of every evaluation
-    int bn_acc_len;
-    int n_mols, D, T, t_first;       // t_first = T-1 for full chains
+    float *table;                    // [T][D]
+    int T, D;
 };
-__global__ void time_embed_kernel(TimeEmbArgs a) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < a.bn_acc_len) a.bn_acc[b] = 0.0;
-    for (int i = b + gridDim.x * blockDim.x; i < a.bn_acc_len; i += gridDim.x * blockDim.x) a.bn_acc[i] = 0.0;
-    if (b == 0 && a.step_ptr) *a.step_cur = *a.step_ptr;
-    if (b >= a.n_mols) return;
-    int t;
-    if (a.step_ptr) { t = a.t_first - *a.step_ptr; a.t_mol[b] = t; } else { t = a.t_mol[b]; }
+__global__ void time_table_kernel(TimeTableArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.T) return;
     const int D = a.D, half = D / 2;
     float e[16], hdn[32];
     const float c = (float)(9.210340371976184 / (half - 1));    // ln(10000) / (half - 1)
@@ -151,26 +142,35 @@ __global__ void time_embed_kernel(TimeEmbArgs a) {
     for (int o = 0; o < D; ++o) {
         float y = a.b2[o];
         for (int i = 0; i < 2 * D; ++i) y += a.w2[o * 2 * D + i] * hdn[i];
-        a.temb[(size_t)b * D + o] = y;
+        a.table[(size_t)t * D + o] = y;
     }
 }
 
-// ligand_atom_emb(cat[one_hot(v), time_emb[batch]])  (molopt_score_model.py:292-301)
+// ligand_atom_emb(cat[one_hot(v), time_emb[batch]])  (molopt_score_model.py:292-301) + the
+// per-evaluation bookkeeping: latch the step counter, clear the batch-norm accumulators.
 struct AtomEmbArgs {
     const float *w, *b;     // [H][C + D], [H]
     const int64_t *v;       // [N]
     const int *mol_of;
-    const float *temb;      // [B][D]
+    const float *ttab;      // [T][D] time-embedding table
+    const int *t_mol;       // [B] timestep per molecule (score API)
+    const int *step_ptr;    // sampling: device step counter, t = t_first - step for every molecule; else nullptr
+    int *step_cur;          // stable copy of the counter for the rest of this step's kernels
+    double *bn_acc;         // zeroed here
     float *h;               // [N][H]
-    int n_atoms, H, C, D;
+    int n_atoms, H, C, D, t_first, bn_acc_len;
 };
 __global__ void atom_embed_kernel(AtomEmbArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    if (idx == 0 && a.step_ptr) *a.step_cur = step;
+    if (idx < a.bn_acc_len) a.bn_acc[idx] = 0.0;
     if (idx >= a.n_atoms * a.H) return;
     const int i = idx / a.H, f = idx % a.H, ld = a.C + a.D;
+    const int t = a.step_ptr ? a.t_first - step : a.t_mol[a.mol_of[i]];
     const float *w = a.w + (size_t)f * ld;
     float y = a.b[f] + w[(int)a.v[i]];
-    const float *te = a.temb + (size_t)a.mol_of[i] * a.D;
+    const float *te = a.ttab + (size_t)t * a.D;
     for (int k = 0; k < a.D; ++k) y += w[a.C + k] * te[k];
     a.h[idx] = y;
 }
@@ -278,29 +278,46 @@ struct VnArgs {
     const float *bn_g, *bn_b;   // [heads]
     const int *mol_of;
     float *pd;              // [N][heads][6]  p (3) and d (3)
-    double *acc;            // [2][heads]  sum of norms, sum of squared norms (this layer)
+    double *acc;            // [kBnReplicas][2][heads] sums of norms / squared norms (this layer), spread over
+                            // replicas because same-address atomics serialise at the memory side
     float *x_out;           // [N][3]
     int n_atoms, heads;
 };
 
-// thread = (atom, channel c); blockDim = 256
-__global__ void vn_stats_kernel(VnArgs a) {
-    __shared__ double red[2][256];
-    const int heads = a.heads, per_blk = 256 / heads;
+// thread = (atom, channel c); 256 threads = 256/heads atoms per block.  The attention rows of the
+// block's atoms and the VN weights are staged in LDS with coalesced 16-byte loads (each thread used to
+// issue ~150 scalar global loads); the double sums go to global memory with one atomic per block and channel.
+constexpr int kVnThreads = 256;
+constexpr int kBnReplicas = 16;
+__global__ void __launch_bounds__(kVnThreads) vn_stats_kernel(VnArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_o[64 * 48];      // up to 64 atoms x 16 rows x 3
+    __shared__ __attribute__((aligned(16))) float s_w[2 * 32 * 16];  // wf_o | wd_o, [heads][16]
+    __shared__ double red[2][kVnThreads];
+    const int heads = a.heads, per_blk = kVnThreads / heads;
     const int la = threadIdx.x / heads, c = threadIdx.x % heads;
-    const int i = blockIdx.x * per_blk + la;
+    const int atom0 = blockIdx.x * per_blk;
+    const int n_here = min(per_blk, a.n_atoms - atom0);
+    for (int i = threadIdx.x; i < n_here * 12; i += kVnThreads)
+        reinterpret_cast<float4 *>(s_o)[i] = reinterpret_cast<const float4 *>(a.o3 + (size_t)atom0 * 48)[i];
+    for (int i = threadIdx.x; i < heads * 16; i += kVnThreads) { s_w[i] = a.wf_o[i]; s_w[32 * 16 + i] = a.wd_o[i]; }
+    __syncthreads();
+    const int i = atom0 + la;
     double nv = 0.0, nv2 = 0.0;
-    if (la < per_blk && i < a.n_atoms) {
-        const float *o = a.o3 + (size_t)i * 48;
+    if (la < n_here) {
+        const float *o = s_o + la * 48;
+        const float *wf = s_w + c * 16, *wd = s_w + 32 * 16 + c * 16;
         const float *psf = a.ps + ((size_t)a.mol_of[i] * 2 * heads + c) * 3;
         const float *psd = psf + heads * 3;
+        const float wfx = a.wf_x[c], wdx = a.wd_x[c];
         float p[3], d[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float pp = a.wf_x[c] * a.x[i * 3 + k], dd = a.wd_x[c] * a.x[i * 3 + k];
+            const float xk = a.x[i * 3 + k];
+            float pp = wfx * xk, dd = wdx * xk;
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pp += a.wf_o[c * 16 + r] * o[r * 3 + k];
-                dd += a.wd_o[c * 16 + r] * o[r * 3 + k];
+                pp += wf[r] * o[r * 3 + k];
+                dd += wd[r] * o[r * 3 + k];
             }
             p[k] = pp + psf[k];
             d[k] = dd + psd[k];
@@ -317,8 +334,9 @@ __global__ void vn_stats_kernel(VnArgs a) {
     if (threadIdx.x < heads) {
         double s = 0.0, s2 = 0.0;
         for (int k = 0; k < per_blk; ++k) { s += red[0][k * heads + threadIdx.x]; s2 += red[1][k * heads + threadIdx.x]; }
-        atomicAdd(a.acc + threadIdx.x, s);
-        atomicAdd(a.acc + heads + threadIdx.x, s2);
+        double *acc = a.acc + (size_t)(blockIdx.x % kBnReplicas) * 2 * heads;
+        atomicAdd(acc + threadIdx.x, s);
+        atomicAdd(acc + heads + threadIdx.x, s2);
     }
 }
 
@@ -331,8 +349,10 @@ __global__ void vn_apply_kernel(VnArgs a) {
     float o[3] = {0.f, 0.f, 0.f};
     if (ok) {
         const double cnt = (double)a.n_atoms;
-        const double mean = a.acc[c] / cnt;
-        double var = a.acc[heads + c] / cnt - mean * mean;
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < kBnReplicas; ++r) { s1 += a.acc[(size_t)r * 2 * heads + c]; s2 += a.acc[(size_t)r * 2 * heads + heads + c]; }
+        const double mean = s1 / cnt;
+        double var = s2 / cnt - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const float meanf = (float)mean;
         const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
@@ -374,7 +394,7 @@ struct DdpmArgs {
     const float *x_t;        // [N][3]
     const int64_t *v_t;      // [N]
     const int *mol_of;
-    const int *t_mol;        // [B]
+    int t_first;             // t = t_first - step for every molecule
     const float *c0, *ct, *logvar, *log_a, *log_1ma, *log_abar, *log_1mabar;   // [T] tables
     const float *eps, *u;    // host-fed noise of ALL steps ([S][N][3], [S][N][C]) or nullptr
     const int *step_cur;     // this step's index (written by time_embed_kernel) or nullptr (= 0)
@@ -391,7 +411,7 @@ __global__ void ddpm_step_kernel(DdpmArgs a) {
     const int step = a.step_cur ? *a.step_cur : 0;
     if (i < a.n_atoms) {
         const int C = a.C;
-        const int t = a.t_mol[a.mol_of[i]];
+        const int t = a.t_first - step;
         const size_t so = (size_t)step * a.n_atoms + i;
         float e3[3], uu[MAXC];
         if (a.eps) {
@@ -465,6 +485,82 @@ __global__ void ddpm_step_kernel(DdpmArgs a) {
         if (a.tr_v) a.tr_v[so] = best;
     }
     if (a.step_ptr && blockIdx.x == 0 && threadIdx.x == 0) *a.step_ptr = step + 1;
+}
+
+// Same step with 16 lanes per atom (one class per lane, C <= 16): the per-class transcendental chains
+// run in parallel and the reductions are DPP row operations.
+__global__ void __launch_bounds__(256) ddpm_step16_kernel(DdpmArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i_raw = gid >> 4, c = gid & 15;
+    const int step = a.step_cur ? *a.step_cur : 0;
+    const bool atom_ok = i_raw < a.n_atoms;
+    const int i = atom_ok ? i_raw : a.n_atoms - 1;
+    const int C = a.C;
+    const bool cls = c < C;
+    const int t = a.t_first - step;
+    const size_t so = (size_t)step * a.n_atoms + i;
+    float eps = 0.f, uu = 0.5f;
+    if (a.eps) {
+        if (c < 3) eps = a.eps[so * 3 + c];
+        if (cls) uu = a.u[so * C + c];
+    } else {
+        Philox ph{(uint32_t)a.seed, (uint32_t)(a.seed >> 32)};
+        uint32_t r[4];
+        if (c < 3) {
+            ph((uint32_t)i, (uint32_t)step, 0u, 0x5eedu, r);
+            const float rad = sqrtf(-2.0f * logf(u01_open(c < 2 ? r[0] : r[2])));
+            const float ang = 6.283185307179586f * u01_half(c < 2 ? r[1] : r[3]);
+            eps = rad * (c == 1 ? sinf(ang) : cosf(ang));
+        }
+        ph((uint32_t)i, (uint32_t)step, (uint32_t)(1 + (c >> 2)), 0x5eedu, r);
+        uu = u01_half(r[c & 3]);
+    }
+    // ---- positions (lanes 0..2)
+    if (c < 3) {
+        const float pp = a.pred_pos[i * 3 + c];
+        const float sig = t != 0 ? expf(0.5f * a.logvar[t]) : 0.f;
+        const float xn = (a.c0[t] * pp + a.ct[t] * a.x_t[i * 3 + c]) + sig * eps;
+        if (atom_ok) {
+            a.x_next[i * 3 + c] = xn;
+            if (a.tr_pos) a.tr_pos[so * 3 + c] = xn;
+            if (a.tr_pos_cond) a.tr_pos_cond[so * 3 + c] = pp;
+        }
+    }
+    // ---- atom types (one class per lane)
+    const float lg = cls ? a.pred_v[(size_t)i * C + c] : -INFINITY;
+    const float mx = seg_max<16>(lg);
+    const float se = seg_sum<16>(cls ? expf(lg - mx) : 0.f);
+    const float lv0 = lg - (mx + logf(se));
+    const int tm1 = t > 0 ? t - 1 : 0;
+    const float logC = logf((float)C);
+    const float la_prev = a.log_abar[tm1], l1_prev = a.log_1mabar[tm1] - logC;
+    const float la_t = a.log_a[t], l1_t = a.log_1ma[t] - logC;
+    const int vt = (int)a.v_t[i];
+    const float A1 = lv0 + la_prev;
+    const float m1 = fmaxf(A1, l1_prev);
+    const float q1 = m1 + logf(expf(A1 - m1) + expf(l1_prev - m1));
+    const float lvt = (c == vt ? 0.f : -69.07755278982137f) + la_t;   // log(clamp(onehot, 1e-30))
+    const float m2 = fmaxf(lvt, l1_t);
+    const float q2 = m2 + logf(expf(lvt - m2) + expf(l1_t - m2));
+    const float un = cls ? q1 + q2 : -INFINITY;
+    const float umx = seg_max<16>(un);
+    const float us = seg_sum<16>(cls ? expf(un - umx) : 0.f);
+    const float lp = un - (umx + logf(us));
+    const float sc = cls ? (-logf(-logf(uu + 1e-30f) + 1e-30f)) + lp : -INFINITY;
+    const float best = seg_max<16>(sc);
+    // first index attaining the maximum (torch argmax tie rule): min over lanes of (sc == best ? c : 99)
+    const float cand = (sc == best) ? (float)c : 99.f;
+    const float win = -seg_max<16>(-cand);
+    if (atom_ok && cls) {
+        if (a.tr_v_cond) a.tr_v_cond[so * C + c] = lg;
+        if (a.tr_v0) a.tr_v0[so * C + c] = lv0;
+        if (a.tr_vt) a.tr_vt[so * C + c] = lp;
+    }
+    if (atom_ok && c == 0) {
+        a.v_next[i] = (int64_t)win;
+        if (a.tr_v) a.tr_v[so] = (int64_t)win;
+    }
+    if (a.step_ptr && gid == 0) *a.step_ptr = step + 1;
 }
 
 // log_sample_categorical (molopt_score_model.py:98-104)

@@ -43,8 +43,9 @@ node_linear_kernel(NodeLinArgs a) {
     constexpr int NT = H / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int ogroups = (a.n_out_tiles + 15) / 16;
-    const int ot = (blockIdx.x % ogroups) * 16 + wave;
+    const int nwave = blockDim.x >> 6;
+    const int ogroups = (a.n_out_tiles + nwave - 1) / nwave;
+    const int ot = (blockIdx.x % ogroups) * nwave + wave;
     const int ag = blockIdx.x / ogroups;
     if (ot >= a.n_out_tiles) return;
     const int n_ct = (a.n_atoms + 15) / 16;
@@ -56,11 +57,19 @@ node_linear_kernel(NodeLinArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) w[t] = ldg4(a.wimg + ((size_t)(ot * NT + t) * 64 + lane) * 4);
 
+    // software pipeline: the activation tile and the per-molecule term of tile ct+1 are loaded while
+    // tile ct runs through the MFMAs (mol_of -> add_mol is a dependent pair of L2 round trips)
     float4 cur[NT], nxt[NT];
+    float4 add_cur = {0.f, 0.f, 0.f, 0.f}, add_nxt = {0.f, 0.f, 0.f, 0.f};
+    int mol_nxt = 0;
     {
         const int atom = min(ct0 * 16 + n, a.n_atoms - 1);
 #pragma unroll
         for (int t = 0; t < NT; ++t) cur[t] = ldg4(a.in + (size_t)atom * H + 16 * t + 4 * g);
+        if (a.add_mol) {
+            add_cur = ldg4(a.add_mol + (size_t)a.mol_of[atom] * a.ld_add + 16 * ot + 4 * g);
+            if (ct0 + 1 < ct1) mol_nxt = a.mol_of[min((ct0 + 1) * 16 + n, a.n_atoms - 1)];
+        }
     }
     SM_STAMP(a.stamps, 1);
     for (int ct = ct0; ct < ct1; ++ct) {
@@ -68,15 +77,13 @@ node_linear_kernel(NodeLinArgs a) {
             const int atom_n = min((ct + 1) * 16 + n, a.n_atoms - 1);
 #pragma unroll
             for (int t = 0; t < NT; ++t) nxt[t] = ldg4(a.in + (size_t)atom_n * H + 16 * t + 4 * g);
+            if (a.add_mol) {
+                add_nxt = ldg4(a.add_mol + (size_t)mol_nxt * a.ld_add + 16 * ot + 4 * g);
+                if (ct + 2 < ct1) mol_nxt = a.mol_of[min((ct + 2) * 16 + n, a.n_atoms - 1)];
+            }
         }
-        const int atom_raw = ct * 16 + n;
-        const bool atom_ok = atom_raw < a.n_atoms;
-        const int atom = atom_ok ? atom_raw : a.n_atoms - 1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (a.add_mol) {
-            const float4 s = ldg4(a.add_mol + (size_t)a.mol_of[atom] * a.ld_add + 16 * ot + 4 * g);
-            acc = f32x4{s.x, s.y, s.z, s.w};
-        }
+        const int atom = ct * 16 + n;
+        f32x4 acc = {add_cur.x, add_cur.y, add_cur.z, add_cur.w};
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc = mfma16(w[t].x, cur[t].x, acc);
@@ -84,12 +91,12 @@ node_linear_kernel(NodeLinArgs a) {
             acc = mfma16(w[t].z, cur[t].z, acc);
             acc = mfma16(w[t].w, cur[t].w, acc);
         }
-        SM_STAMP(a.stamps, 2 + 2 * (ct - ct0 < 2 ? ct - ct0 : 2));
-        if (atom_ok) stg4(a.out + (size_t)atom * a.ld_out + 16 * ot + 4 * g, float4{acc[0], acc[1], acc[2], acc[3]});
-        SM_STAMP(a.stamps, 3 + 2 * (ct - ct0 < 2 ? ct - ct0 : 2));
+        if (atom < a.n_atoms) stg4(a.out + (size_t)atom * a.ld_out + 16 * ot + 4 * g, float4{acc[0], acc[1], acc[2], acc[3]});
 #pragma unroll
         for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
+        add_cur = add_nxt;
     }
+    SM_STAMP(a.stamps, 2);
 }
 
 struct NodeMlpArgs {
@@ -269,10 +276,11 @@ node_chain_kernel(NodeChainArgs a) {
             for (int i = 0; i < NT * 4; ++i) v[i] = (v[i] > 20.f ? v[i] : log1pf(expf(v[i]))) - 0.6931471805599453f;
         }
     };
-    auto gemm_hid = [&](const float *wimg, const float (&v)[NT * 4], f32x4 acc) {
-        float4 w[NT];
+    auto load_w = [&](const float *wimg, float4 (&w)[NT]) {        // this wave's 16 x H block of a [.][H] image
 #pragma unroll
         for (int t = 0; t < NT; ++t) w[t] = ldg4(wimg + ((size_t)(ot * NT + t) * 64 + lane) * 4);
+    };
+    auto gemm_hid = [&](const float4 (&w)[NT], const float (&v)[NT * 4], f32x4 acc) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc = mfma16(w[t].x, v[4 * t + 0], acc);
@@ -298,13 +306,15 @@ node_chain_kernel(NodeChainArgs a) {
         acc = gemm_rows(a.w1img, 2 * NT, NT, x, acc);
         stg4(bufA + row + f0, float4{acc[0], acc[1], acc[2], acc[3]});
     }
+    float4 wn[NT];                                   // next stage's weight block, fetched across the barrier
+    load_w(a.w2img, wn);
     __syncthreads();
     {
         float hid[NT * 4];
         read_row(bufA, hid);
         activate(hid, NODE_LN_RELU, a.ln_g, a.ln_b);
         const float4 b = ldg4(a.b2 + f0);
-        f32x4 acc = gemm_hid(a.w2img, hid, f32x4{b.x, b.y, b.z, b.w});
+        f32x4 acc = gemm_hid(wn, hid, f32x4{b.x, b.y, b.z, b.w});
         const float4 hn = {acc[0] + hres.x, acc[1] + hres.y, acc[2] + hres.z, acc[3] + hres.w};
         stg4(bufB + row + f0, hn);
         if (atom_ok) stg4(a.h_out + (size_t)atom * H + f0, hn);
@@ -333,10 +343,11 @@ node_chain_kernel(NodeChainArgs a) {
         const NodeFollow &F = a.f[k];
         if (ot >= F.nt2) continue;
         float hid[NT * 4];
+        load_w(F.w2img, wn);
         read_row(k == 0 ? bufA : bufC, hid);
         activate(hid, F.mode, F.ln_g, F.ln_b);
         const float4 b = ldg4(F.b2 + f0);
-        const f32x4 acc = gemm_hid(F.w2img, hid, f32x4{b.x, b.y, b.z, b.w});
+        const f32x4 acc = gemm_hid(wn, hid, f32x4{b.x, b.y, b.z, b.w});
         if (!atom_ok) continue;
         if (f0 + 4 <= F.n_store && (F.ld_out & 3) == 0) {
             stg4(F.out + (size_t)atom * F.ld_out + f0, float4{acc[0], acc[1], acc[2], acc[3]});

@@ -2,6 +2,8 @@
 """Developer tool: per-kernel-class launch times (HIP events, eager) + graph-replay step time.
     python tools/kbench.py [--batch 256] [--steps 20] [--opt edge_waves=8] ..."""
 import argparse, os, sys, time
+if '--stamps-build' in sys.argv:
+    os.environ['SHAPEMOL_STAMPS'] = '1'; sys.argv.remove('--stamps-build')
 import torch, yaml
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -24,7 +24,7 @@ st = m.debug_read("kstamps", (4096 * 16, 8), np.uint64).astype(np.int64)
 st = st[st[:, 0] > 0]
 t0 = st[:, 0].min()
 print(f"waves stamped: {len(st)}; all times in us relative to the earliest stamp 0")
-names = {0: ["start", "weights+tile0 loaded", "tile0 mfma", "tile0 stored", "tile1 mfma", "tile1 stored", "tile2 mfma", "tile2 stored"],
+names = {0: ["start", "weights+tile0 loaded", "all tiles done (stores drained)", "-", "-", "-", "-", "-"],
          1: ["start", "weights in LDS", "k hidden (gather+GEMM1+LN)", "k GEMM2", "logits+softmax", "v hidden", "v GEMM2", "reduce+store (job 1)"]}
 nm = names[0 if a.sel == 0 else 1]
 for k in range(8):
