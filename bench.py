@@ -170,13 +170,24 @@ def main():
         dom_ms, dom_n = prof[dom]
         avg_s = dom_ms * 1e-3 / dom_n
         f_exec_total, f_edge_x2h = executed_flops_per_atom_step(dm.H, dm.L, dm.k, dm.G, dm.heads, dm.C, dm.S)
+        HH = dm.H * dm.H
         per_launch = {"edge_x2h": f_edge_x2h * dm.k * n_atoms,
-                      "edge_h2x": ((dm.G * dm.H + dm.H * dm.H) + (dm.G * dm.H + dm.H * dm.heads)) * 2 * dm.k * n_atoms}
+                      "edge_h2x": ((dm.G * dm.H + HH) + (dm.G * dm.H + dm.H * dm.heads)) * 2 * dm.k * n_atoms,
+                      "node_chain": 14 * HH * n_atoms,          # out MLP (2H->H->H) + two follow-up MLPs (H->H->H)
+                      "node_pre": 16 * HH * n_atoms}            # 8H x H paired products (the first launch does 4H)
         flops = per_launch.get(dom, 0.0)
         ach = flops / avg_s / 1e12 if flops else 0.0
+        traffic = None                                          # HBM bytes per launch from the committed PMC passes
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "pmc_traffic.json")))
+            if args.batch == 256:
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r01_final/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
             "flops_per_launch_executed": flops, "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_n,
             "share_of_step": round(dom_ms / tot_ms, 3),
             "step_tflops_executed": round(f_exec_total * n_atoms / sec_per_step / 1e12, 3),
