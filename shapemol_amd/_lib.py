@@ -8,8 +8,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshapemol_hip_stamps.so" if os.environ.get("SHAPEMOL_STAMPS") == "1"
-                        else "libshapemol_hip.so")
+# SHAPEMOL_LIB selects a diagnostic build (tools/ only), e.g. "stamps" or "abl1"
+_variant = os.environ.get("SHAPEMOL_LIB") or ("stamps" if os.environ.get("SHAPEMOL_STAMPS") == "1" else "")
+LIB_PATH = os.path.join(_HERE, f"libshapemol_hip_{_variant}.so" if _variant else "libshapemol_hip.so")
 ABI_VERSION = 1
 
 EXPORTS = (

@@ -5,6 +5,7 @@
 #include "../../include/shapemol_hip.h"
 #include "sm_device.h"
 #include "sm_edge.h"
+#include "sm_edge_bf16.h"
 #include "sm_node.h"
 #include "sm_misc.h"
 
@@ -116,7 +117,8 @@ struct DevLayer {
     size_t sk_x2h, sv_x2h, sk_h2x, sv_h2x;   // [H][SL] shape columns of the first layers
     size_t bk_x2h, bv_x2h, bk_h2x, bv_h2x;   // first-layer biases [H]
     DevMlpImg q_x2h, q_h2x, no;
-    size_t blob_x2h, blob_h2x;
+    size_t blob_x2h, blob_h2x;        // fp32 edge kernels (sm_edge.h): both MLPs of a kernel in one LDS image
+    size_t img_kx, img_vx, img_kh, img_vh;   // bf16-split phase kernels (sm_edge_bf16.h): one image per MLP
     size_t vn_f, vn_d;                // original [heads][cin]
     size_t wf_x, wd_x, wf_o, wd_o, bn_g, bn_b;
 };
@@ -190,6 +192,57 @@ void pack_edge_mlp(const Mlp &m, int H, int kv_in, bool perm_heads, float *wr, f
     }
 }
 
+// exact 3-way bf16 split of a float by truncation; returns the three 16-bit patterns
+void split3_host(float w, uint16_t (&p)[3]) {
+    float r = w;
+    for (int i = 0; i < 3; ++i) {
+        uint32_t u; std::memcpy(&u, &r, 4);
+        const uint32_t hi = u & 0xFFFF0000u;
+        p[i] = (uint16_t)(hi >> 16);
+        float h; std::memcpy(&h, &hi, 4);
+        r = r - h;
+    }
+}
+
+// one edge MLP -> EdgePhaseImage (sm_edge_bf16.h)
+template <int H>
+size_t pack_phase_image(Image &im, const Mlp &m, int kv_in, bool perm_heads) {
+    constexpr int NT = H / 16, NB = NT / 2;
+    const int nt2 = perm_heads ? 1 : NT;
+    const int o_wr = 0, o_g = o_wr + NT * 5 * 64, o_b = o_g + H, o_b2 = o_b + H, o_w2 = o_b2 + nt2 * 16;
+    const int total = o_w2 + 3 * nt2 * NB * 256;
+    const size_t o = im.alloc(total);
+    float *d = &im.d[o];
+    for (int t = 0; t < NT; ++t)
+        for (int s = 0; s < 5; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                d[o_wr + (t * 5 + s) * 64 + lane] = m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * s + (lane >> 4)];
+    std::memcpy(d + o_g, m.g, H * sizeof(float));
+    std::memcpy(d + o_b, m.be, H * sizeof(float));
+    for (int i = 0; i < nt2 * 16; ++i) {
+        const int row = perm_heads ? head_of_row(i, NT) : i;
+        d[o_b2 + i] = row < 0 ? 0.f : m.l2.b[row];
+    }
+    uint32_t *w2 = reinterpret_cast<uint32_t *>(d + o_w2);
+    for (int t2 = 0; t2 < nt2; ++t2)
+        for (int b = 0; b < NB; ++b)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int mrow = lane & 15, g = lane >> 4;
+                const int row = perm_heads ? head_of_row(mrow, NT) : 16 * t2 + mrow;
+                for (int q = 0; q < 4; ++q) {
+                    uint16_t pc[2][3];
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * q + e;
+                        const int col = 16 * (2 * b + (j >> 2)) + 4 * g + (j & 3);
+                        split3_host(row < 0 ? 0.f : m.l2.w[(size_t)row * H + col], pc[e]);
+                    }
+                    for (int piece = 0; piece < 3; ++piece)
+                        w2[(((size_t)(piece * nt2 + t2) * NB + b) * 64 + lane) * 4 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+                }
+            }
+    return o;
+}
+
 template <int H>
 void build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D) {
     const int G = c.num_r_gaussian, SL = c.shape_latent_dim, S = c.shape_dim, hd = c.n_heads;
@@ -226,6 +279,8 @@ void build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, 
         pack_edge_mlp(L.xk, H, kv, false, b + B::K_WR, b + B::K_W2, b + B::K_G, b + B::K_B, b + B::K_B2);
         pack_edge_mlp(L.xv, H, kv, true, b + B::V_WR, b + B::V_W2, b + B::V_G, b + B::V_B, b + B::V_B2);
     }
+    D.img_kx = pack_phase_image<H>(im, L.hk, kv, false); D.img_vx = pack_phase_image<H>(im, L.hv, kv, false);
+    D.img_kh = pack_phase_image<H>(im, L.xk, kv, false); D.img_vh = pack_phase_image<H>(im, L.xv, kv, true);
     D.vn_f = im.put(L.vn_f, (size_t)hd * cin); D.vn_d = im.put(L.vn_d, (size_t)hd * cin);
     D.bn_g = im.put(L.bn_g, hd); D.bn_b = im.put(L.bn_b, hd);
     D.wf_x = im.alloc(hd); D.wd_x = im.alloc(hd); D.wf_o = im.alloc((size_t)hd * 16); D.wd_o = im.alloc((size_t)hd * 16);
@@ -257,6 +312,7 @@ struct shapemol_ctx {
     int *mol_of = nullptr, *mol_off = nullptr, *t_mol = nullptr, *nbr = nullptr, *steps = nullptr;
     float *temb = nullptr, *inv = nullptr, *add0 = nullptr, *addp = nullptr, *ps = nullptr, *ew = nullptr;
     float *h_a = nullptr, *h_b = nullptr, *pre0 = nullptr, *preAB = nullptr, *q_x = nullptr, *q_h = nullptr, *att = nullptr, *o3 = nullptr, *pd = nullptr;
+    float *alpha = nullptr;     // [N*KP][2][NT] attention weights handed from the key phase to the value phase
     float *x_a = nullptr, *x_b = nullptr, *x_state = nullptr, *pred_pos = nullptr, *pred_v = nullptr;
     int64_t *v_state = nullptr;
     unsigned long long *stamps = nullptr;   // [1024][2] diagnostic clock stamps
@@ -268,7 +324,7 @@ struct shapemol_ctx {
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 8;
+    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 8, edge_bf16 = 1;
     int num_cu = 256;
     // profiling
     bool prof_on = false;
@@ -320,7 +376,7 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
         A(&c->steps, 4) || A(&c->temb, capB * g.time_emb_dim) || A(&c->inv, capB * g.shape_latent_dim) ||
         A(&c->add0, (size_t)capB * 4 * H) || A(&c->addp, (size_t)L * capB * 8 * H) || A(&c->ps, (size_t)L * capB * 2 * hd * 3) || A(&c->ew, capN * c->KP) ||
         A(&c->h_a, capN * H) || A(&c->h_b, capN * H) || A(&c->pre0, capN * 4 * H) || A(&c->preAB, capN * 8 * H) || A(&c->q_x, capN * H) || A(&c->q_h, capN * H) ||
-        A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
+        A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->alpha, capN * c->KP * 2 * (H / 16)) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
         A(&c->x_b, capN * 3) || A(&c->x_state, capN * 3) || A(&c->pred_pos, capN * 3) ||
         A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * kBnReplicas * 2 * hd))
         return 1;
@@ -337,7 +393,16 @@ int set_edge_attr(int KP) {
 #define SETATTR1(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge_attention_t1_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b0)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_attention_t1_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b1));
-    if (KP == 8) { SETATTR1(8) } else if (KP == 16) { SETATTR1(16) } else { SETATTR(32) }
+#define SETATTR2(K)                                                                                                   \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_K>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_VX>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_VH>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, 1>::TOTAL * 4));
+#define SETATTR3(K)                                                                                                   \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4));
+    if (KP == 8) { SETATTR1(8) SETATTR2(8) SETATTR3(8) } else if (KP == 16) { SETATTR1(16) SETATTR2(16) SETATTR3(16) } else { SETATTR(32) }
+#undef SETATTR2
+#undef SETATTR3
 #undef SETATTR
 #undef SETATTR1
     return 0;
@@ -356,6 +421,29 @@ int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {
     if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 8, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
     else if (KP == 16) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 16, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
     else LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    return 0;
+}
+
+template <int H, int MODE>
+int launch_phase(shapemol_ctx *c, hipStream_t s, const char *nm, const EdgePhaseArgs &a) {
+    const int KP = c->KP, apj = 16 / KP;
+    const int njobs = (a.n_atoms + apj - 1) / apj, waves = c->edge_threads / 64;
+    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
+    const size_t shm = EdgePhaseImage<H, (MODE == PH_VH ? 1 : H / 16)>::TOTAL * sizeof(float);
+    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_phase_kernel<H, 8, MODE>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    else LAUNCH(nm, hipLaunchKernelGGL((edge_phase_kernel<H, 16, MODE>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    return 0;
+}
+
+template <int H, bool H2X>
+int launch_fused(shapemol_ctx *c, hipStream_t s, const EdgeFusedArgs &a) {
+    const int KP = c->KP, apj = 16 / KP;
+    const int njobs = (a.n_atoms + apj - 1) / apj, waves = c->edge_threads / 64;
+    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
+    const size_t shm = (EdgePhaseImage<H, H / 16>::TOTAL + (H2X ? EdgePhaseImage<H, 1>::TOTAL : 0)) * sizeof(float);
+    const char *nm = H2X ? "edge_h2x" : "edge_x2h";
+    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 8, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    else LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 16, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
     return 0;
 }
 
@@ -453,7 +541,19 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     for (int l = 0; l < nlay; ++l) {
         const DevLayer &Dl = c->dm.layer[l];
         const bool last = (l == nlay - 1), has_next = !last;
-        {   // x2h attention
+        const bool phases = c->edge_bf16 && KP <= 16;
+        if (phases && c->edge_bf16 == 1) {   // x2h attention, key and value phase in one launch
+            EdgeFusedArgs fa{c->P(Dl.img_kx), c->P(Dl.img_vx), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew,
+                             c->alpha, c->att, n, l == 0 ? 4 * H : 8 * H};
+            if (launch_fused<H, false>(c, s, fa)) return 1;
+        } else if (phases) {   // x2h attention: key phase -> alpha, value phase -> att (separate launches)
+            const float *pre = l == 0 ? c->pre0 : c->preAB + 4 * H;
+            const int ldp = l == 0 ? 4 * H : 8 * H;
+            EdgePhaseArgs pk{c->P(Dl.img_kx), pre, c->q_x, cur_x, c->nbr, c->ew, c->alpha, nullptr, n, ldp, 0, H};
+            if (launch_phase<H, PH_K>(c, s, "edge_x2h_k", pk)) return 1;
+            EdgePhaseArgs pv{c->P(Dl.img_vx), pre, nullptr, cur_x, c->nbr, c->ew, c->alpha, c->att, n, ldp, 2 * H, 3 * H};
+            if (launch_phase<H, PH_VX>(c, s, "edge_x2h_v", pv)) return 1;
+        } else {   // x2h attention (fp32 MFMA kernels)
             EdgeArgs e{c->P(Dl.blob_x2h), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew, c->att, n,
                        l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
             if (launch_edge<H, false>(c, s, e)) return 1;
@@ -475,7 +575,15 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
                                  c->preAB, 8 * H, (has_next && l + 1 < L ? 8 : 4) * NT, n, nullptr)) return 1;
         }
-        {   // h2x attention
+        if (phases && c->edge_bf16 == 1) {   // h2x attention, both images resident in LDS
+            EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H};
+            if (launch_fused<H, true>(c, s, fa)) return 1;
+        } else if (phases) {   // h2x attention (separate launches)
+            EdgePhaseArgs pk{c->P(Dl.img_kh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, nullptr, n, 8 * H, 0, H};
+            if (launch_phase<H, PH_K>(c, s, "edge_h2x_k", pk)) return 1;
+            EdgePhaseArgs pv{c->P(Dl.img_vh), c->preAB, nullptr, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H, 2 * H, 3 * H};
+            if (launch_phase<H, PH_VH>(c, s, "edge_h2x_v", pv)) return 1;
+        } else {   // h2x attention (fp32 MFMA kernels)
             EdgeArgs e{c->P(Dl.blob_h2x), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->o3, n, 8 * H,
                        (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
             if (launch_edge<H, true>(c, s, e)) return 1;
@@ -697,6 +805,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail("shapemol_set_option: null argument");
     const std::string k(name);
     if (k == "stop_layer") c->stop_layer = (int)value;
+    else if (k == "edge_bf16") c->edge_bf16 = (int)value;
     else if (k == "lin_waves") { if (value < 1 || value > 16) return fail("lin_waves must be 1..16"); c->lin_waves = (int)value; }
     else if (k == "stamps") c->stamp_on = (int)value;
     else if (k == "kstamp_sel") c->kstamp_sel = (int)value;

@@ -103,12 +103,12 @@ SM_DEV float seg_max(float v) {
 // (inline asm: the builtin folds swap(v, v) to (v, v); the s_nop covers the VALU-write hazard.)
 SM_DEV float sum_xor16(float v) {
     float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
 SM_DEV float sum_xor32(float v) {
     float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
 // sum over the four lane groups (same n, g = 0..3)
@@ -202,3 +202,69 @@ struct Philox {
 };
 SM_DEV float u01_open(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)
 SM_DEV float u01_half(uint32_t x) { return (x >> 8) * (1.0f / 16777216.0f); }            // [0,1)
+
+// ---- fp32-accurate products on the bf16 matrix cores ------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the VECTOR rate and never co-executes with VALU work (rocprofv3:
+// SQ_VALU_MFMA_COEXEC_CYCLES = 0 for every fp32-MFMA kernel here), so an fp32-MFMA kernel pays
+// matrix cycles + vector cycles.  v_mfma_f32_16x16x32_bf16 is 16x faster per FLOP and does overlap.
+// A float is split EXACTLY into three bf16 pieces by truncation (8 + 8 + 8 significand bits):
+//     x = hi + mid + lo,   hi = x & 0xFFFF0000,  mid = (x - hi) & 0xFFFF0000,  lo = trunc_bf16(x - hi - mid)
+// and x*w is the sum of the six piece products of total order <= 2 (hh, hm, mh, hl, lh, mm); the dropped
+// ones are below 2^-24 |x w|.  Piece products are exact in fp32 and the MFMA accumulates in fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+SM_DEV f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// {low half = upper 16 bits of x0, high half = upper 16 bits of x1}
+SM_DEV unsigned pack_hi16(unsigned x0, unsigned x1) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
+
+// eight floats (k = 0..7 of a lane's k-slot) -> three bf16x8 B fragments
+SM_DEV void split3_bf16(const float (&v)[8], u32x4 &hi, u32x4 &mid, u32x4 &lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = v[2 * q], x1 = v[2 * q + 1];
+        const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+        const float r1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+        const unsigned m0 = __builtin_bit_cast(unsigned, r0), m1 = __builtin_bit_cast(unsigned, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, m0 & 0xFFFF0000u);
+        const float s1 = r1 - __builtin_bit_cast(float, m1 & 0xFFFF0000u);
+        hi[q] = pack_hi16(u0, u1);
+        mid[q] = pack_hi16(m0, m1);
+        lo[q] = pack_hi16(__builtin_bit_cast(unsigned, s0), __builtin_bit_cast(unsigned, s1));
+    }
+}
+
+// acc[t2] += W2[16-row block t2] * act with the split weight image (LDS)
+//   w[(((piece * NT2 + t2) * NB + b) * 64 + lane) * 4 + q]  (u32, two bf16 each), NB = NT / 2 k-steps of 32;
+//   element j of lane (m, g) at k-step b is piece(W2[16*t2 + m][16*(2b + (j >> 2)) + 4g + (j & 3)]):
+//   the k order inside a step is chosen so that the B operand is the lane's own D-layout registers
+//   8b .. 8b+7 (tiles 2b and 2b+1), i.e. again no data movement between Linear -> LN -> ReLU -> Linear.
+template <int NT, int NT2>
+SM_DEV void gemm_bf16x6(const unsigned *w, const float (&act)[NT * 4], f32x4 (&acc)[NT2], int lane) {
+    constexpr int NB = NT / 2;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act[8 * b + j];
+        u32x4 bh, bm, bl;
+        split3_bf16(v, bh, bm, bl);
+#pragma unroll
+        for (int t2 = 0; t2 < NT2; ++t2) {
+            const u32x4 ah = *reinterpret_cast<const u32x4 *>(w + (((0 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+            const u32x4 am = *reinterpret_cast<const u32x4 *>(w + (((1 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+            const u32x4 al = *reinterpret_cast<const u32x4 *>(w + (((2 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+            f32x4 c = acc[t2];
+            c = mfma_bf16(al, bh, c);      // smallest terms first
+            c = mfma_bf16(am, bm, c);
+            c = mfma_bf16(ah, bl, c);
+            c = mfma_bf16(am, bh, c);
+            c = mfma_bf16(ah, bm, c);
+            c = mfma_bf16(ah, bh, c);
+            acc[t2] = c;
+        }
+    }
+}

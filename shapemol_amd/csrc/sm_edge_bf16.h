@@ -1,0 +1,407 @@
+// Edge attention as per-MLP PHASE kernels with the second Linear on the bf16 matrix cores.
+//
+// Same semantics and formulation as sm_edge.h (reference: models/uni_transformer.py:48-81 for x2h,
+// :121-151 for h2x).  Differences:
+//   * the H x H (or heads x H) second Linear of each edge MLP is evaluated as six bf16 MFMA products of
+//     exactly split operands (sm_device.h, gemm_bf16x6): fp32-level accuracy at ~2.7x the fp32-MFMA
+//     rate, on the matrix pipe, so the LayerNorm / softmax / reduction VALU work overlaps with it;
+//   * the split weights take 6 bytes per element, so only ONE MLP fits in LDS: the key path and the
+//     value path are separate phases (launches) that hand the attention weights over through a small
+//     global buffer  alpha[N * KP][2][NT]  (16 floats per edge slot at H = 128):
+//         PH_K  : logits + per-atom softmax over the neighbour slots           -> alpha
+//         PH_VX : x2h values, sum_j alpha * e_w * v_ij                          -> att [N][H]
+//         PH_VH : h2x values (one per head), sum_j alpha * e_w * v_ij * rel_x   -> o3  [N][16][3]
+// One job = the KP <= 16 neighbour slots of 16 / KP centre atoms = one 16-column tile, as in
+// edge_attention_t1_kernel; loads of a job are issued before the weight image is copied to LDS.
+#pragma once
+#include "sm_device.h"
+
+enum EdgePhase { PH_K = 0, PH_VX = 1, PH_VH = 2 };
+
+struct EdgePhaseArgs {
+    const float *image;     // packed weights of this MLP (EdgePhaseImage)
+    const float *pre;       // node pre-products, row stride ld_pre
+    const float *q;         // [N][H]            (PH_K)
+    const float *x;         // [N][3]
+    const int *nbr;         // [N][KP]
+    const float *ew;        // [N][KP]           (value phases)
+    float *alpha;           // [N*KP][2][NT]     written by PH_K, read by the value phases
+    float *out;             // PH_VX: [N][H]; PH_VH: [N][16][3]
+    int n_atoms, ld_pre, col_a, col_b;   // column offsets of the centre / neighbour product inside a pre row
+};
+
+// LDS image of ONE edge MLP, in 32-bit words
+template <int H, int NT2>
+struct EdgePhaseImage {
+    static constexpr int NT = H / 16, NB = NT / 2;
+    static constexpr int O_WR = 0;                      // [NT][5][64] fp32 A fragments of W1[:, 0:20]
+    static constexpr int O_G = O_WR + NT * 5 * 64;      // gamma[H]
+    static constexpr int O_B = O_G + H;                 // beta[H]
+    static constexpr int O_B2 = O_B + H;                // b2[NT2 * 16]
+    static constexpr int O_W2 = O_B2 + NT2 * 16;        // 3 pieces x [NT2][NB][64][4] u32 (two bf16 each)
+    static constexpr int TOTAL = O_W2 + 3 * NT2 * NB * 256;
+};
+
+template <int H, int KP, int MODE>
+__global__ void __launch_bounds__(768)
+edge_phase_kernel(EdgePhaseArgs a) {
+    static_assert(KP == 8 || KP == 16, "single-tile jobs");
+    constexpr int NT = H / 16;
+    constexpr int NT2 = MODE == PH_VH ? 1 : NT;
+    using IM = EdgePhaseImage<H, NT2>;
+    constexpr int APJ = 16 / KP, SEGW = KP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int njobs = (a.n_atoms + APJ - 1) / APJ;
+    const int jstride = gridDim.x * nwave;
+    const float inv_sqrt_dh = 0.35355339059327373f;   // 1/sqrt(8)
+
+    int job = blockIdx.x * nwave + wave;
+    bool have = job < njobs;
+    int atom = 0, jn = 0, edge = 0;
+    bool atom_ok = false, ok = false;
+    float xi[3], xj[3], ewv = 0.f;
+    float4 ga[NT], gb[NT];
+    float4 al4[2];                                     // attention weights of this lane's edge (value phases)
+
+    auto issue_loads = [&](int jb) {
+        const int atom_raw = jb * APJ + n / SEGW;
+        atom_ok = atom_raw < a.n_atoms;
+        atom = atom_ok ? atom_raw : a.n_atoms - 1;
+        edge = atom * KP + n % SEGW;
+        const int jraw = a.nbr[edge];
+        ok = atom_ok && jraw >= 0;
+        jn = ok ? jraw : atom;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { xi[k] = a.x[atom * 3 + k]; xj[k] = a.x[jn * 3 + k]; }
+        const float *pi = a.pre + (size_t)atom * a.ld_pre + a.col_a, *pj = a.pre + (size_t)jn * a.ld_pre + a.col_b;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { ga[t] = ldg4(pi + 16 * t + 4 * g); gb[t] = ldg4(pj + 16 * t + 4 * g); }
+        if constexpr (MODE != PH_K) {
+            ewv = a.ew[edge];
+            const float *ap = a.alpha + (size_t)edge * 2 * NT + (g >> 1) * NT;
+            if constexpr (MODE == PH_VX) {
+#pragma unroll
+                for (int i = 0; i < (NT + 3) / 4; ++i) al4[i] = ldg4(ap + 4 * i);
+            } else {
+                if constexpr (NT >= 8) al4[0] = ldg4(ap + (NT / 2) * (g & 1));
+                else { al4[0] = float4{0.f, 0.f, 0.f, 0.f}; al4[0].x = ap[(NT / 2) * (g & 1)]; }
+            }
+        }
+    };
+    if (have) issue_loads(job);
+    copy_to_lds(lds, a.image, IM::TOTAL / 4, threadIdx.x, blockDim.x);
+    __syncthreads();
+
+    const unsigned *w2 = reinterpret_cast<const unsigned *>(lds) + IM::O_W2;
+    while (have) {
+        asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
+        const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
+        const float d = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
+        float rb[5];
+        rbf_dlayout(d, g, rb);
+        // first Linear (fp32 MFMA, K = 20) + LayerNorm + ReLU
+        float hid[NT * 4];
+        {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma16(lds[IM::O_WR + (t * 5 + s) * 64 + lane], rb[s], acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
+                hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
+            }
+        }
+        float4 qv[NT];
+        if constexpr (MODE == PH_K) {        // query row: in flight during LayerNorm + second Linear
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qv[t] = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g);
+        }
+        ln_relu_dlayout<NT>(hid, lds + IM::O_G, lds + IM::O_B, g);
+        // second Linear on the bf16 matrix cores (six exact piece products)
+        f32x4 acc2[NT2];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+            const float4 b2 = ldg4(lds + IM::O_B2 + 16 * t + 4 * g);
+            acc2[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
+        }
+        gemm_bf16x6<NT, NT2>(w2, hid, acc2, lane);
+
+        const int cur_atom = atom, cur_edge = edge;
+        const bool cur_atom_ok = atom_ok, cur_ok = ok;
+        const float w = ok ? ewv : 0.f;
+        job += jstride;
+        have = job < njobs;
+        if constexpr (MODE == PH_K) {
+            // logit of head 2t + (g >> 1): 4 dims here + 4 dims in the partner lane group (g ^ 1)
+            float alpha[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float p = qv[t].x * acc2[t][0] + qv[t].y * acc2[t][1] + qv[t].z * acc2[t][2] + qv[t].w * acc2[t][3];
+                p = sum_xor16(p);
+                p = cur_ok ? p * inv_sqrt_dh : -INFINITY;
+                const float mx = seg_max<SEGW>(p);
+                const float e = cur_ok ? expf(p - mx) : 0.f;
+                const float s = seg_sum<SEGW>(e);
+                alpha[t] = s > 0.f ? e / s : 0.f;
+            }
+            if (cur_atom_ok && (g & 1) == 0) {
+                float *ap = a.alpha + (size_t)cur_edge * 2 * NT + (g >> 1) * NT;
+                if constexpr (NT % 4 == 0) {
+#pragma unroll
+                    for (int i = 0; i < NT / 4; ++i)
+                        stg4(ap + 4 * i, float4{alpha[4 * i], alpha[4 * i + 1], alpha[4 * i + 2], alpha[4 * i + 3]});
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) ap[t] = alpha[t];
+                }
+            }
+            if (have) issue_loads(job);
+        } else if constexpr (MODE == PH_VX) {
+            const float al[8] = {al4[0].x, al4[0].y, al4[0].z, al4[0].w, al4[1].x, al4[1].y, al4[1].z, al4[1].w};
+            float o[NT * 4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float aw = al[t % 8] * w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[4 * t + r] = seg_sum<SEGW>(aw * acc2[t][r]);
+            }
+            if (cur_atom_ok && (n % SEGW) == 0) {
+                float *op = a.out + (size_t)cur_atom * H;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    stg4(op + 16 * t + 4 * g, float4{o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]});
+            }
+            if (have) issue_loads(job);
+        } else {
+            // value row 4g + r belongs to head 2*((NT/2)*(g&1) + r) + (g>>1): al4[0] holds exactly those
+            // alphas (rows with r >= NT/2 are zero padding)
+            const float al[4] = {al4[0].x, al4[0].y, al4[0].z, al4[0].w};
+            float o[12];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float av = r < NT / 2 ? al[r] * w * acc2[0][r] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[3 * r + k] = seg_sum<SEGW>(av * rel[k]);
+            }
+            if (cur_atom_ok && (n % SEGW) == 0) {
+                float *op = a.out + (size_t)cur_atom * 48 + 12 * g;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    stg4(op + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
+            }
+            if (have) issue_loads(job);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fused variant: key phase and value phase of one attention in ONE launch.  alpha never crosses
+// workgroups (the wave that produced the weights of a job consumes them), so the hand-over only needs
+// the workgroup barrier that the weight swap in LDS needs anyway:
+//   x2h : [copy K image] barrier | key phase of all jobs | barrier [copy V image over it] barrier | value phase
+//   h2x : the value image is small (heads x H): both images are resident, no swap
+// -------------------------------------------------------------------------------------------------
+struct EdgeFusedArgs {
+    const float *image_k, *image_v;
+    const float *pre;       // node pre-products [N][ld_pre]: A_k | B_k | A_v | B_v at column offsets 0, H, 2H, 3H
+    const float *q;         // [N][H]
+    const float *x;         // [N][3]
+    const int *nbr;         // [N][KP]
+    const float *ew;        // [N][KP]
+    float *alpha;           // [N*KP][2][NT] scratch
+    float *out;             // x2h: [N][H]; h2x: [N][16][3]
+    int n_atoms, ld_pre;
+};
+
+template <int H, int KP, bool H2X>
+__global__ void __launch_bounds__(768)
+edge_fused_kernel(EdgeFusedArgs a) {
+    static_assert(KP == 8 || KP == 16, "single-tile jobs");
+    constexpr int NT = H / 16;
+    constexpr int NT2V = H2X ? 1 : NT;
+    using IMK = EdgePhaseImage<H, NT>;
+    using IMV = EdgePhaseImage<H, NT2V>;
+    constexpr int V_BASE = H2X ? IMK::TOTAL : 0;       // h2x: value image behind the key image; x2h: swapped in
+    constexpr int APJ = 16 / KP, SEGW = KP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int njobs = (a.n_atoms + APJ - 1) / APJ;
+    const int jstride = gridDim.x * nwave;
+    const int job0 = blockIdx.x * nwave + wave;
+    const float inv_sqrt_dh = 0.35355339059327373f;   // 1/sqrt(8)
+
+    int atom = 0, jn = 0, edge = 0;
+    bool atom_ok = false, ok = false;
+    float xi[3], xj[3];
+    float4 ga[NT], gb[NT];
+
+    auto issue_loads = [&](int jb, int col_a, int col_b) {
+        const int atom_raw = jb * APJ + n / SEGW;
+        atom_ok = atom_raw < a.n_atoms;
+        atom = atom_ok ? atom_raw : a.n_atoms - 1;
+        edge = atom * KP + n % SEGW;
+        const int jraw = a.nbr[edge];
+        ok = atom_ok && jraw >= 0;
+        jn = ok ? jraw : atom;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { xi[k] = a.x[atom * 3 + k]; xj[k] = a.x[jn * 3 + k]; }
+        const float *pi = a.pre + (size_t)atom * a.ld_pre + col_a, *pj = a.pre + (size_t)jn * a.ld_pre + col_b;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { ga[t] = ldg4(pi + 16 * t + 4 * g); gb[t] = ldg4(pj + 16 * t + 4 * g); }
+    };
+    // hidden = ReLU(LN(A_i + B_j + W_r rbf)) with the image at `img`
+    auto hidden = [&](const float *img, const float (&rb)[5], float (&hid)[NT * 4]) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(img[IMK::O_WR + (t * 5 + s) * 64 + lane], rb[s], acc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
+            hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
+        }
+        ln_relu_dlayout<NT>(hid, img + IMK::O_G, img + IMK::O_B, g);
+    };
+
+    int job = job0;
+    bool have = job < njobs;
+    if (have) issue_loads(job, 0, H);
+    copy_to_lds(lds, a.image_k, IMK::TOTAL / 4, threadIdx.x, blockDim.x);
+    if constexpr (H2X) copy_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, threadIdx.x, blockDim.x);
+    __syncthreads();
+
+    // ---- key phase ---------------------------------------------------------------------------------
+    while (have) {
+        asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
+        const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
+        float rb[5];
+        rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), g, rb);
+        float hid[NT * 4];
+        hidden(lds, rb, hid);
+        float4 qv[NT];                       // query row: in flight during the second Linear
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qv[t] = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g);
+        f32x4 kacc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 b2 = ldg4(lds + IMK::O_B2 + 16 * t + 4 * g);
+            kacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
+        }
+        gemm_bf16x6<NT, NT>(reinterpret_cast<const unsigned *>(lds) + IMK::O_W2, hid, kacc, lane);
+        // logit of head 2t + (g >> 1): 4 dims here + 4 dims in the partner lane group (g ^ 1)
+        float alpha[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float p = qv[t].x * kacc[t][0] + qv[t].y * kacc[t][1] + qv[t].z * kacc[t][2] + qv[t].w * kacc[t][3];
+            p = sum_xor16(p);
+            p = ok ? p * inv_sqrt_dh : -INFINITY;
+            const float mx = seg_max<SEGW>(p);
+            const float e = ok ? expf(p - mx) : 0.f;
+            const float s = seg_sum<SEGW>(e);
+            alpha[t] = s > 0.f ? e / s : 0.f;
+        }
+        if (atom_ok && (g & 1) == 0) {
+            float *ap = a.alpha + (size_t)edge * 2 * NT + (g >> 1) * NT;
+            if constexpr (NT % 4 == 0) {
+#pragma unroll
+                for (int i = 0; i < NT / 4; ++i)
+                    stg4(ap + 4 * i, float4{alpha[4 * i], alpha[4 * i + 1], alpha[4 * i + 2], alpha[4 * i + 3]});
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ap[t] = alpha[t];
+            }
+        }
+        job += jstride;
+        have = job < njobs;
+        if (have) issue_loads(job, 0, H);
+    }
+
+    // ---- hand-over: value-phase loads of the first job fly across the weight swap ------------------
+    job = job0;
+    have = job < njobs;
+    if (have) issue_loads(job, 2 * H, 3 * H);
+    __syncthreads();                         // key weights no longer needed; alpha stores of this wave drained
+    if constexpr (!H2X) {
+        copy_to_lds(lds, a.image_v, IMV::TOTAL / 4, threadIdx.x, blockDim.x);
+        __syncthreads();
+    }
+
+    // ---- value phase -------------------------------------------------------------------------------
+    const float *imv = lds + V_BASE;
+    while (have) {
+        asm volatile("" ::: "memory");
+        const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
+        float rb[5];
+        rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), g, rb);
+        const float w = ok ? a.ew[edge] : 0.f;
+        const float *ap = a.alpha + (size_t)edge * 2 * NT + (g >> 1) * NT;
+        float al[NT];
+        if constexpr (!H2X) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) al[t] = ap[t];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NT; ++r) al[r] = r < NT / 2 ? ap[(NT / 2) * (g & 1) + r] : 0.f;
+        }
+        float hid[NT * 4];
+        hidden(imv, rb, hid);
+        f32x4 vacc[NT2V];
+#pragma unroll
+        for (int t = 0; t < NT2V; ++t) {
+            const float4 b2 = ldg4(imv + IMV::O_B2 + 16 * t + 4 * g);
+            vacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
+        }
+        gemm_bf16x6<NT, NT2V>(reinterpret_cast<const unsigned *>(imv) + IMV::O_W2, hid, vacc, lane);
+        const int cur_atom = atom;
+        const bool store = atom_ok && (n % SEGW) == 0;
+        if constexpr (!H2X) {
+            float o[NT * 4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float aw = al[t] * w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[4 * t + r] = seg_sum<SEGW>(aw * vacc[t][r]);
+            }
+            if (store) {
+                float *op = a.out + (size_t)cur_atom * H;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    stg4(op + 16 * t + 4 * g, float4{o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]});
+            }
+        } else {
+            // value row 4g + r belongs to head 2*((NT/2)*(g&1) + r) + (g>>1); rows with r >= NT/2 are padding
+            float o[12];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float av = r < NT / 2 ? al[r % NT] * w * vacc[0][r] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[3 * r + k] = seg_sum<SEGW>(av * rel[k]);
+            }
+            if (store) {
+                float *op = a.out + (size_t)cur_atom * 48 + 12 * g;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    stg4(op + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
+            }
+        }
+        job += jstride;
+        have = job < njobs;
+        if (have) issue_loads(job, 2 * H, 3 * H);
+    }
+}
