@@ -562,14 +562,15 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             float *dst = (last && out_h) ? out_h : (cur_h == c->h_a ? c->h_b : c->h_a);
             NodeChainArgs na{};
             na.att = c->att; na.h = cur_h; na.h_out = dst; na.n_atoms = n;
+            na.stamps = (c->kstamp_sel == 3 && l == 0) ? c->kstamps : nullptr;
             na.w1img = c->P(Dl.no.w1img); na.b1 = c->P(Dl.no.b1); na.ln_g = c->P(Dl.no.g); na.ln_b = c->P(Dl.no.be);
             na.w2img = c->P(Dl.no.w2img); na.b2 = c->P(Dl.no.b2);
             na.f[0] = follow_of(c, Dl.q_h2x, NODE_LN_RELU, c->q_h, H, H);
             na.n_follow = 1;
             if (has_next) { na.f[1] = follow_of(c, c->dm.layer[l + 1].q_x2h, NODE_LN_RELU, c->q_x, H, H); na.n_follow = 2; }
             else if (out_v) { na.f[1] = follow_of(c, c->dm.vhead, NODE_SSP, out_v, C, C); na.n_follow = 2; v_done = true; }
-            const int n_ct = (n + 15) / 16, teams = NodeMlpLds<H>::TEAMS;
-            LAUNCH("node_chain", hipLaunchKernelGGL(node_chain_kernel<H>, dim3((n_ct + teams - 1) / teams), dim3(kNodeThreads), 0, s, na));
+            const int n_ct = (n + 15) / 16;
+            LAUNCH("node_chain", hipLaunchKernelGGL(node_chain_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), 0, s, na));
             cur_h = dst;
             // per-node halves of the edge MLPs' first Linear: h2x of this layer | x2h of the next one
             if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,

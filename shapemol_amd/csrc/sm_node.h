@@ -229,42 +229,49 @@ struct NodeChainArgs {
     float *h_out;                                         // [N][H]
     NodeFollow f[2];
     int n_follow, n_atoms;
+    unsigned long long *stamps;   // diagnostic build only
 };
 
+// One workgroup = NT waves (one per 16-row block of output features) x CHAIN_COLS column tiles: every weight
+// block is read from L2 once per workgroup and applied to all its column tiles (the per-CU L2 read rate,
+// ~70 GB/s, is what bounds this kernel: 448 KB of weights per workgroup at H = 128).
+constexpr int CHAIN_COLS = 2;
+
 template <int H>
-__global__ void __launch_bounds__(kNodeThreads)
+__global__ void __launch_bounds__(H * 4)
 node_chain_kernel(NodeChainArgs a) {
-    constexpr int NT = H / 16;
-    using L = NodeMlpLds<H>;
-    __shared__ __attribute__((aligned(16))) float bufA[L::TOTAL], bufB[L::TOTAL], bufC[L::TOTAL];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NT = H / 16, CC = CHAIN_COLS;
+    constexpr int XS = H + 16;                            // row stride of the exchange tiles
+    constexpr int XS2 = 2 * H + 16;                       // row stride of the [att | h] input tile
+    __shared__ __attribute__((aligned(16))) float bufA[CC * 16 * XS], bufB[CC * 16 * XS], bufC[CC * 16 * XS];
+    __shared__ __attribute__((aligned(16))) float tile[CC * 16 * XS2];
+    const int lane = threadIdx.x & 63, ot = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int team = (wave / NT) % L::TEAMS, ot = wave % NT;
-    const bool mirror = (wave / NT) >= L::TEAMS;
-    const int ct = blockIdx.x * L::TEAMS + team;
-    const int atom_raw = ct * 16 + n;
-    const bool atom_ok = atom_raw < a.n_atoms && !mirror;
-    const int atom = atom_raw < a.n_atoms ? atom_raw : a.n_atoms - 1;
-    const int row = (team * 16 + n) * L::XS;
+    const int ct0 = blockIdx.x * CC;
     const int f0 = 16 * ot + 4 * g;
 
-    auto gemm_rows = [&](const float *wimg, int ntk, int kt0, const float4 (&x)[NT], f32x4 acc) {
-        float4 w[NT];
+    auto load_w = [&](const float *wimg, int ntk, int kt0, float4 (&w)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) w[t] = ldg4(wimg + ((size_t)(ot * ntk + kt0 + t) * 64 + lane) * 4);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc = mfma16(w[t].x, x[t].x, acc);
-            acc = mfma16(w[t].y, x[t].y, acc);
-            acc = mfma16(w[t].z, x[t].z, acc);
-            acc = mfma16(w[t].w, x[t].w, acc);
-        }
-        return acc;
     };
-    auto read_row = [&](const float *buf, float (&v)[NT * 4]) {
+    // acc[c] += W * X_c for both column tiles, B operand streamed from LDS rows (stride xs)
+    auto gemm_lds = [&](const float4 (&w)[NT], const float *x0, int xs, f32x4 (&acc)[CC]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float4 q = ldg4(buf + row + 16 * t + 4 * g);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float4 x = ldg4(x0 + (c * 16 + n) * xs + 16 * t + 4 * g);
+                acc[c] = mfma16(w[t].x, x.x, acc[c]);
+                acc[c] = mfma16(w[t].y, x.y, acc[c]);
+                acc[c] = mfma16(w[t].z, x.z, acc[c]);
+                acc[c] = mfma16(w[t].w, x.w, acc[c]);
+            }
+        }
+    };
+    auto read_row = [&](const float *buf, int c, float (&v)[NT * 4]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 q = ldg4(buf + (c * 16 + n) * XS + 16 * t + 4 * g);
             v[4 * t] = q.x; v[4 * t + 1] = q.y; v[4 * t + 2] = q.z; v[4 * t + 3] = q.w;
         }
     };
@@ -276,10 +283,6 @@ node_chain_kernel(NodeChainArgs a) {
             for (int i = 0; i < NT * 4; ++i) v[i] = (v[i] > 20.f ? v[i] : log1pf(expf(v[i]))) - 0.6931471805599453f;
         }
     };
-    auto load_w = [&](const float *wimg, float4 (&w)[NT]) {        // this wave's 16 x H block of a [.][H] image
-#pragma unroll
-        for (int t = 0; t < NT; ++t) w[t] = ldg4(wimg + ((size_t)(ot * NT + t) * 64 + lane) * 4);
-    };
     auto gemm_hid = [&](const float4 (&w)[NT], const float (&v)[NT * 4], f32x4 acc) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -290,71 +293,105 @@ node_chain_kernel(NodeChainArgs a) {
         }
         return acc;
     };
+    auto atom_of = [&](int c) { return min((ct0 + c) * 16 + n, a.n_atoms - 1); };
+    auto atom_ok = [&](int c) { return (ct0 + c) * 16 + n < a.n_atoms; };
 
-    // ---- stage 1: node_output MLP -------------------------------------------------------------
-    float4 hres;
-    {
-        float4 x[NT];
-        const float4 b = ldg4(a.b1 + f0);
-        f32x4 acc = {b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) x[t] = ldg4(a.att + (size_t)atom * H + 16 * t + 4 * g);
-        acc = gemm_rows(a.w1img, 2 * NT, 0, x, acc);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) x[t] = ldg4(a.h + (size_t)atom * H + 16 * t + 4 * g);
-        hres = ldg4(a.h + (size_t)atom * H + f0);                // residual: this wave's 4 features of h
-        acc = gemm_rows(a.w1img, 2 * NT, NT, x, acc);
-        stg4(bufA + row + f0, float4{acc[0], acc[1], acc[2], acc[3]});
+    SM_TICK(a.stamps, 0);
+    // ---- stage 1: node_output MLP; every stage's weight block is requested one stage ahead ----------
+    float4 wa[NT], wb[NT], wc[NT];
+    load_w(a.w1img, 2 * NT, 0, wa);
+    load_w(a.w1img, 2 * NT, NT, wb);
+    {   // [att | h] tiles of the workgroup -> LDS
+        constexpr int R4 = 2 * H / 4;
+        for (int idx = threadIdx.x; idx < CC * 16 * R4; idx += NT * 64) {
+            const int ar = idx / R4, c4 = idx % R4;
+            const int at = min(ct0 * 16 + ar, a.n_atoms - 1);
+            const float4 v = c4 < H / 4 ? ldg4(a.att + (size_t)at * H + 4 * c4) : ldg4(a.h + (size_t)at * H + 4 * (c4 - H / 4));
+            stg4(tile + ar * XS2 + 4 * c4, v);
+        }
     }
-    float4 wn[NT];                                   // next stage's weight block, fetched across the barrier
-    load_w(a.w2img, wn);
+    const float4 b1 = ldg4(a.b1 + f0);
+    load_w(a.w2img, NT, 0, wc);                                  // second Linear of the output MLP
     __syncthreads();
     {
-        float hid[NT * 4];
-        read_row(bufA, hid);
-        activate(hid, NODE_LN_RELU, a.ln_g, a.ln_b);
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{b1.x, b1.y, b1.z, b1.w};
+        gemm_lds(wa, tile, XS2, acc);
+        gemm_lds(wb, tile + H, XS2, acc);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) stg4(bufA + (c * 16 + n) * XS + f0, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
+    }
+    if (a.n_follow > 0) load_w(a.f[0].w1img, NT, 0, wa);         // first Linears of the follow-up MLPs
+    if (a.n_follow > 1) load_w(a.f[1].w1img, NT, 0, wb);
+    SM_TICK(a.stamps, 1);
+    __syncthreads();
+    SM_TICK(a.stamps, 2);
+    {
         const float4 b = ldg4(a.b2 + f0);
-        f32x4 acc = gemm_hid(wn, hid, f32x4{b.x, b.y, b.z, b.w});
-        const float4 hn = {acc[0] + hres.x, acc[1] + hres.y, acc[2] + hres.z, acc[3] + hres.w};
-        stg4(bufB + row + f0, hn);
-        if (atom_ok) stg4(a.h_out + (size_t)atom * H + f0, hn);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            float hid[NT * 4];
+            read_row(bufA, c, hid);
+            activate(hid, NODE_LN_RELU, a.ln_g, a.ln_b);
+            const f32x4 acc = gemm_hid(wc, hid, f32x4{b.x, b.y, b.z, b.w});
+            const float4 hres = ldg4(tile + (c * 16 + n) * XS2 + H + f0);      // residual: h is in the input tile
+            const float4 hn = {acc[0] + hres.x, acc[1] + hres.y, acc[2] + hres.z, acc[3] + hres.w};
+            stg4(bufB + (c * 16 + n) * XS + f0, hn);
+            if (atom_ok(c)) stg4(a.h_out + (size_t)atom_of(c) * H + f0, hn);
+        }
     }
+    SM_TICK(a.stamps, 3);
     __syncthreads();
+    SM_TICK(a.stamps, 4);
     if (a.n_follow == 0) return;
 
     // ---- stage 2: follow-up MLPs on the new h ------------------------------------------------------
+    const bool on0 = ot < a.f[0].nt2, on1 = a.n_follow > 1 && ot < a.f[1].nt2;
+    if (on0) load_w(a.f[0].w2img, NT, 0, wc);
     {
-        float4 x[NT];
+        const float4 b = ldg4(a.f[0].b1 + f0);
+        f32x4 acc[CC];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) x[t] = ldg4(bufB + row + 16 * t + 4 * g);
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{b.x, b.y, b.z, b.w};
+        gemm_lds(wa, bufB, XS, acc);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (k < a.n_follow) {
-                const float4 b = ldg4(a.f[k].b1 + f0);
-                const f32x4 acc = gemm_rows(a.f[k].w1img, NT, 0, x, f32x4{b.x, b.y, b.z, b.w});
-                stg4((k == 0 ? bufA : bufC) + row + f0, float4{acc[0], acc[1], acc[2], acc[3]});
+        for (int c = 0; c < CC; ++c) stg4(bufA + (c * 16 + n) * XS + f0, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
+    }
+    if (on1) load_w(a.f[1].w2img, NT, 0, wa);
+    if (a.n_follow > 1) {
+        const float4 b = ldg4(a.f[1].b1 + f0);
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{b.x, b.y, b.z, b.w};
+        gemm_lds(wb, bufB, XS, acc);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) stg4(bufC + (c * 16 + n) * XS + f0, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
+    }
+    SM_TICK(a.stamps, 5);
+    __syncthreads();
+    SM_TICK(a.stamps, 6);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!(k == 0 ? on0 : on1)) continue;
+        const NodeFollow &F = a.f[k];
+        const float4 b = ldg4(F.b2 + f0);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            float hid[NT * 4];
+            read_row(k == 0 ? bufA : bufC, c, hid);
+            activate(hid, F.mode, F.ln_g, F.ln_b);
+            const f32x4 acc = gemm_hid(k == 0 ? wc : wa, hid, f32x4{b.x, b.y, b.z, b.w});
+            if (!atom_ok(c)) continue;
+            const int atom = atom_of(c);
+            if (f0 + 4 <= F.n_store && (F.ld_out & 3) == 0) {
+                stg4(F.out + (size_t)atom * F.ld_out + f0, float4{acc[0], acc[1], acc[2], acc[3]});
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (f0 + r < F.n_store) F.out[(size_t)atom * F.ld_out + f0 + r] = acc[r];
             }
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (k >= a.n_follow) break;
-        const NodeFollow &F = a.f[k];
-        if (ot >= F.nt2) continue;
-        float hid[NT * 4];
-        load_w(F.w2img, wn);
-        read_row(k == 0 ? bufA : bufC, hid);
-        activate(hid, F.mode, F.ln_g, F.ln_b);
-        const float4 b = ldg4(F.b2 + f0);
-        const f32x4 acc = gemm_hid(wn, hid, f32x4{b.x, b.y, b.z, b.w});
-        if (!atom_ok) continue;
-        if (f0 + 4 <= F.n_store && (F.ld_out & 3) == 0) {
-            stg4(F.out + (size_t)atom * F.ld_out + f0, float4{acc[0], acc[1], acc[2], acc[3]});
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (f0 + r < F.n_store) F.out[(size_t)atom * F.ld_out + f0 + r] = acc[r];
-        }
-    }
+    SM_TICK(a.stamps, 7);
 }

@@ -26,7 +26,8 @@ t0 = st[:, 0].min()
 print(f"waves stamped: {len(st)}; all times in us relative to the earliest stamp 0")
 names = {0: ["start", "weights+tile0 loaded", "all tiles done (stores drained)", "-", "-", "-", "-", "-"],
          1: ["start", "weights in LDS", "k hidden (gather+GEMM1+LN)", "k GEMM2", "logits+softmax", "v hidden", "v GEMM2", "reduce+store (job 1)"]}
-nm = names[0 if a.sel == 0 else 1]
+names[3] = ["start", "stage1 GEMM1 issued (+W2 loads)", "after barrier 1", "h' computed+stored", "after barrier 2", "follow GEMM1s issued", "after barrier 3", "end"]
+nm = names[a.sel if a.sel in names else 1]
 for k in range(8):
     col = st[:, k]; col = col[col > 0]
     if len(col) == 0: continue
