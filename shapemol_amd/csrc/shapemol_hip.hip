@@ -324,7 +324,7 @@ struct shapemol_ctx {
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 8, edge_bf16 = 1;
+    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 16, edge_bf16 = 1;
     int num_cu = 256;
     // profiling
     bool prof_on = false;

@@ -37,64 +37,60 @@ struct NodeLinArgs {
     unsigned long long *stamps;   // diagnostic build only
 };
 
+constexpr int kLinChunk = 8;      // column tiles staged in LDS at a time (shared by the workgroup's waves)
+
 template <int H>
 __global__ void __launch_bounds__(kNodeThreads)
 node_linear_kernel(NodeLinArgs a) {
     constexpr int NT = H / 16;
+    constexpr int XS = H + 16;
+    __shared__ __attribute__((aligned(16))) float tiles[kLinChunk * 16 * XS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int nwave = blockDim.x >> 6;
     const int ogroups = (a.n_out_tiles + nwave - 1) / nwave;
-    const int ot = (blockIdx.x % ogroups) * nwave + wave;
+    const int ot_raw = (blockIdx.x % ogroups) * nwave + wave;
+    const bool ot_ok = ot_raw < a.n_out_tiles;
+    const int ot = ot_ok ? ot_raw : a.n_out_tiles - 1;
     const int ag = blockIdx.x / ogroups;
-    if (ot >= a.n_out_tiles) return;
     const int n_ct = (a.n_atoms + 15) / 16;
     const int ct0 = ag * a.tiles_per_group, ct1 = min(ct0 + a.tiles_per_group, n_ct);
-    if (ct0 >= ct1) return;
     SM_STAMP(a.stamps, 0);
 
     float4 w[NT];                                                   // this wave's weight block, resident
 #pragma unroll
     for (int t = 0; t < NT; ++t) w[t] = ldg4(a.wimg + ((size_t)(ot * NT + t) * 64 + lane) * 4);
 
-    // software pipeline: the activation tile and the per-molecule term of tile ct+1 are loaded while
-    // tile ct runs through the MFMAs (mol_of -> add_mol is a dependent pair of L2 round trips)
-    float4 cur[NT], nxt[NT];
-    float4 add_cur = {0.f, 0.f, 0.f, 0.f}, add_nxt = {0.f, 0.f, 0.f, 0.f};
-    int mol_nxt = 0;
-    {
-        const int atom = min(ct0 * 16 + n, a.n_atoms - 1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) cur[t] = ldg4(a.in + (size_t)atom * H + 16 * t + 4 * g);
-        if (a.add_mol) {
-            add_cur = ldg4(a.add_mol + (size_t)a.mol_of[atom] * a.ld_add + 16 * ot + 4 * g);
-            if (ct0 + 1 < ct1) mol_nxt = a.mol_of[min((ct0 + 1) * 16 + n, a.n_atoms - 1)];
+    for (int cb = ct0; cb < ct1; cb += kLinChunk) {
+        const int nc = min(kLinChunk, ct1 - cb);
+        __syncthreads();                                            // previous chunk fully consumed
+        // the workgroup's activation tiles -> LDS once (every wave needs all of them as its B operand)
+        for (int idx = threadIdx.x; idx < nc * 16 * (H / 4); idx += blockDim.x) {
+            const int ar = idx / (H / 4), c4 = idx % (H / 4);
+            const int at = min(cb * 16 + ar, a.n_atoms - 1);
+            stg4(tiles + ar * XS + 4 * c4, ldg4(a.in + (size_t)at * H + 4 * c4));
         }
-    }
-    SM_STAMP(a.stamps, 1);
-    for (int ct = ct0; ct < ct1; ++ct) {
-        if (ct + 1 < ct1) {
-            const int atom_n = min((ct + 1) * 16 + n, a.n_atoms - 1);
+        __syncthreads();
+        // per-molecule term of the first tile; the next tile's is fetched while this one multiplies
+        float4 add_cur = {0.f, 0.f, 0.f, 0.f}, add_nxt = {0.f, 0.f, 0.f, 0.f};
+        if (a.add_mol) add_cur = ldg4(a.add_mol + (size_t)a.mol_of[min(cb * 16 + n, a.n_atoms - 1)] * a.ld_add + 16 * ot + 4 * g);
+        for (int c = 0; c < nc; ++c) {
+            if (a.add_mol && c + 1 < nc)
+                add_nxt = ldg4(a.add_mol + (size_t)a.mol_of[min((cb + c + 1) * 16 + n, a.n_atoms - 1)] * a.ld_add + 16 * ot + 4 * g);
+            const float *xrow = tiles + (c * 16 + n) * XS;
+            f32x4 acc = {add_cur.x, add_cur.y, add_cur.z, add_cur.w};
 #pragma unroll
-            for (int t = 0; t < NT; ++t) nxt[t] = ldg4(a.in + (size_t)atom_n * H + 16 * t + 4 * g);
-            if (a.add_mol) {
-                add_nxt = ldg4(a.add_mol + (size_t)mol_nxt * a.ld_add + 16 * ot + 4 * g);
-                if (ct + 2 < ct1) mol_nxt = a.mol_of[min((ct + 2) * 16 + n, a.n_atoms - 1)];
+            for (int t = 0; t < NT; ++t) {
+                const float4 x = ldg4(xrow + 16 * t + 4 * g);
+                acc = mfma16(w[t].x, x.x, acc);
+                acc = mfma16(w[t].y, x.y, acc);
+                acc = mfma16(w[t].z, x.z, acc);
+                acc = mfma16(w[t].w, x.w, acc);
             }
+            const int atom = (cb + c) * 16 + n;
+            if (ot_ok && atom < a.n_atoms) stg4(a.out + (size_t)atom * a.ld_out + 16 * ot + 4 * g, float4{acc[0], acc[1], acc[2], acc[3]});
+            add_cur = add_nxt;
         }
-        const int atom = ct * 16 + n;
-        f32x4 acc = {add_cur.x, add_cur.y, add_cur.z, add_cur.w};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc = mfma16(w[t].x, cur[t].x, acc);
-            acc = mfma16(w[t].y, cur[t].y, acc);
-            acc = mfma16(w[t].z, cur[t].z, acc);
-            acc = mfma16(w[t].w, cur[t].w, acc);
-        }
-        if (atom < a.n_atoms) stg4(a.out + (size_t)atom * a.ld_out + 16 * ot + 4 * g, float4{acc[0], acc[1], acc[2], acc[3]});
-#pragma unroll
-        for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
-        add_cur = add_nxt;
     }
     SM_STAMP(a.stamps, 2);
 }
