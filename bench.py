@@ -190,6 +190,11 @@ def main():
             "traffic_source": "profiles/r01_final/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
             "flops_per_launch_executed": flops, "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_n,
             "share_of_step": round(dom_ms / tot_ms, 3),
+            "note": "achieved/peak are fp32 FLOPs of the kernel's algorithm against the dense fp32 MFMA peak; the edge kernels "
+                    "run their H x H second Linears as six exact bf16 piece products on the bf16 matrix cores (fp32-level accuracy), "
+                    "see matrix_pipe",
+            "matrix_pipe": ({"executed_bf16_tflops": round(6 * 2 * (2 * HH) * dm.k * n_atoms / avg_s / 1e12, 1), "bf16_dense_peak": 2500.0}
+                            if dom == "edge_x2h" else None),
             "step_tflops_executed": round(f_exec_total * n_atoms / sec_per_step / 1e12, 3),
             "step_tflops_ref_equiv": round(reference_flops_per_atom_step(dm.k, dm.L) * n_atoms / sec_per_step / 1e12, 3),
             "breakdown_ms_per_step": {k: round(v[0] / max(1, args.profile_steps), 4) for k, v in prof.items()},

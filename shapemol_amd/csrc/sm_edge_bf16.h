@@ -294,9 +294,6 @@ edge_fused_kernel(EdgeFusedArgs a) {
         rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), g, rb);
         float hid[NT * 4];
         hidden(lds, rb, hid);
-        float4 qv[NT];                       // query row: in flight during the second Linear
-#pragma unroll
-        for (int t = 0; t < NT; ++t) qv[t] = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g);
         f32x4 kacc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -308,7 +305,8 @@ edge_fused_kernel(EdgeFusedArgs a) {
         float alpha[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float p = qv[t].x * kacc[t][0] + qv[t].y * kacc[t][1] + qv[t].z * kacc[t][2] + qv[t].w * kacc[t][3];
+            const float4 qq = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g);     // L2/L1-hot, shared by the atom's lanes
+            float p = qq.x * kacc[t][0] + qq.y * kacc[t][1] + qq.z * kacc[t][2] + qq.w * kacc[t][3];
             p = sum_xor16(p);
             p = ok ? p * inv_sqrt_dh : -INFINITY;
             const float mx = seg_max<SEGW>(p);
@@ -329,6 +327,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
         }
         job += jstride;
         have = job < njobs;
+        asm volatile("" ::: "memory");       // keep the next job's loads below this job's tail (register pressure)
         if (have) issue_loads(job, 0, H);
     }
 
@@ -402,6 +401,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
         }
         job += jstride;
         have = job < njobs;
+        asm volatile("" ::: "memory");
         if (have) issue_loads(job, 2 * H, 3 * H);
     }
 }
