@@ -108,7 +108,13 @@ int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, co
 
 /* ---- diagnostics (used by the parity tests and the bench; not needed by a caller) ---- */
 /* options: "stop_layer" (run only the first v layers of the next _score; -1 = all),
- *          "edge_waves" (waves per workgroup of the edge kernels, tuning). */
+ *          "edge_bf16"  (1 = fused key/value edge kernel with exactly split bf16 second Linears [default],
+ *                        2 = the same arithmetic as separate key / value launches, 0 = fp32-MFMA edge kernels;
+ *                        k > 16 always uses the fp32 kernels),
+ *          "edge_waves" (1..12 waves per workgroup of the edge kernels, tuning),
+ *          "lin_waves"  (1..16 waves per workgroup of node_linear_kernel, tuning),
+ *          "stamps", "kstamp_sel" (clock-stamp diagnostics; only meaningful in the --stamps build).
+ * Changing an option invalidates a captured graph (the next _sample re-captures). */
 int shapemol_set_option(shapemol_ctx *ctx, const char *name, int64_t value);
 /* Copy an internal device buffer of the last _score to HOST memory (synchronises the device).
  * names: "nbr" (N,KP) i32, "ew" (N,KP) f32, "h" (N,H), "x" (N,3), "pre" (N,4H), "q" (N,H),
