@@ -114,6 +114,7 @@ struct DevMlpImg { size_t w1img, b1, g, be, w2img, b2; int nt2; };   // MFMA A-f
 struct DevLayer {
     size_t pre_x2h, pre_h2x;          // images of [4H][H]: first-layer node blocks (k_i, k_j, v_i, v_j)
     size_t lin_img;                   // image of [8H][H]: pre_h2x of this layer followed by pre_x2h of the next
+    size_t lin6_img, pre6_x2h;        // the same (and pre_x2h alone) as split bf16 images (node_linear6_kernel)
     size_t sk_x2h, sv_x2h, sk_h2x, sv_h2x;   // [H][SL] shape columns of the first layers
     size_t bk_x2h, bv_x2h, bk_h2x, bv_h2x;   // first-layer biases [H]
     DevMlpImg q_x2h, q_h2x, no;
@@ -243,6 +244,27 @@ size_t pack_phase_image(Image &im, const Mlp &m, int kv_in, bool perm_heads) {
     return o;
 }
 
+// fp32 A-fragment image of W[rows][K] (pack_image) -> split bf16 image of node_linear6_kernel:
+//   [(((ot * 3 + piece) * NB + b) * 64 + lane) * 4 + q] u32, element order of gemm_bf16x6
+size_t pack_linear6_image(Image &im, size_t src, int rows, int K) {
+    const int ntk = K / 16, NB = K / 32, nto = rows / 16;
+    const size_t o = im.alloc((size_t)nto * 3 * NB * 256);
+    uint32_t *w = reinterpret_cast<uint32_t *>(&im.d[o]);
+    for (int ot = 0; ot < nto; ++ot)
+        for (int b = 0; b < NB; ++b)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int q = 0; q < 4; ++q) {
+                    uint16_t pc[2][3];
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * q + e, t = 2 * b + (j >> 2), r = j & 3;
+                        split3_host(im.d[src + ((size_t)(ot * ntk + t) * 64 + lane) * 4 + r], pc[e]);
+                    }
+                    for (int piece = 0; piece < 3; ++piece)
+                        w[(((size_t)(ot * 3 + piece) * NB + b) * 64 + lane) * 4 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+                }
+    return o;
+}
+
 template <int H>
 void build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D) {
     const int G = c.num_r_gaussian, SL = c.shape_latent_dim, S = c.shape_dim, hd = c.n_heads;
@@ -324,7 +346,7 @@ struct shapemol_ctx {
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 16, edge_bf16 = 1;
+    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 16, edge_bf16 = 1, lin_bf16 = 1;
     int num_cu = 256;
     // profiling
     bool prof_on = false;
@@ -400,6 +422,7 @@ int set_edge_attr(int KP) {
 #define SETATTR3(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4));
+    HIPCHK(hipFuncSetAttribute((const void *)node_linear6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin6Chunk * 3 * H * 32));
     if (KP == 8) { SETATTR1(8) SETATTR2(8) SETATTR3(8) } else if (KP == 16) { SETATTR1(16) SETATTR2(16) SETATTR3(16) } else { SETATTR(32) }
 #undef SETATTR2
 #undef SETATTR3
@@ -460,15 +483,20 @@ int launch_mlp2(shapemol_ctx *c, hipStream_t s, const char *name, const DevMlpIm
 }
 
 template <int H>
-int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float *in, const float *wimg, const float *add_mol,
+int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float *in, const float *wimg, const float *wimg6, const float *add_mol,
                   int ld_add, float *out, int ld_out, int n_out_tiles, int n_atoms, unsigned long long *stamps) {
     const int nwave = c->lin_waves;
     const int n_ct = (n_atoms + 15) / 16, ogroups = (n_out_tiles + nwave - 1) / nwave;
     const int want_groups = std::max(1, c->num_cu / ogroups);
     const int tpg = std::max(1, (n_ct + want_groups - 1) / want_groups);
     const int agroups = (n_ct + tpg - 1) / tpg;
-    NodeLinArgs a{in, wimg, add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps};
-    LAUNCH(name, hipLaunchKernelGGL(node_linear_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), 0, s, a));
+    NodeLinArgs a{in, c->lin_bf16 ? wimg6 : wimg, add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps};
+    if (c->lin_bf16) {
+        const size_t shm = (size_t)std::min(tpg, kLin6Chunk) * 3 * H * 32;
+        LAUNCH(name, hipLaunchKernelGGL(node_linear6_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a));
+    } else {
+        LAUNCH(name, hipLaunchKernelGGL(node_linear_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), 0, s, a));
+    }
     return 0;
 }
 
@@ -534,7 +562,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     bool v_done = false;
     if (nlay > 0) {   // prologue: per-node products and queries of the first x2h attention
         const DevLayer &D0 = c->dm.layer[0];
-        if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(D0.pre_x2h), c->add0, 4 * H, c->pre0, 4 * H, 4 * NT, n,
+        if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(D0.pre_x2h), c->P(D0.pre6_x2h), c->add0, 4 * H, c->pre0, 4 * H, 4 * NT, n,
                              c->kstamp_sel == 0 ? c->kstamps : nullptr)) return 1;
         if (launch_mlp2<H, 1>(c, s, "node_q", D0.q_x2h, cur_h, nullptr, NODE_LN_RELU, nullptr, c->q_x, H, H, n)) return 1;
     }
@@ -573,7 +601,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             LAUNCH("node_chain", hipLaunchKernelGGL(node_chain_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), 0, s, na));
             cur_h = dst;
             // per-node halves of the edge MLPs' first Linear: h2x of this layer | x2h of the next one
-            if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
+            if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->P(Dl.lin6_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
                                  c->preAB, 8 * H, (has_next && l + 1 < L ? 8 : 4) * NT, n, nullptr)) return 1;
         }
         if (phases && c->edge_bf16 == 1) {   // h2x attention, both images resident in LDS
@@ -699,6 +727,10 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
         if (l + 1 < cfg->num_layers) std::memcpy(&im.d[o + blk], &im.d[dm.layer[l + 1].pre_x2h], blk * sizeof(float));
         dm.layer[l].lin_img = o;
     }
+    for (int l = 0; l < cfg->num_layers; ++l) {
+        dm.layer[l].lin6_img = pack_linear6_image(im, dm.layer[l].lin_img, 8 * H, H);
+        dm.layer[l].pre6_x2h = l == 0 ? pack_linear6_image(im, dm.layer[l].pre_x2h, 4 * H, H) : 0;
+    }
     im.alloc(64);
     if (hipMalloc((void **)&c->d_img, im.d.size() * sizeof(float)) != hipSuccess) { delete c; return fail("hipMalloc(weights) failed"); }
     if (hipMemcpy(c->d_img, im.d.data(), im.d.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { hipFree(c->d_img); delete c; return fail("hipMemcpy(weights) failed"); }
@@ -807,6 +839,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     const std::string k(name);
     if (k == "stop_layer") c->stop_layer = (int)value;
     else if (k == "edge_bf16") c->edge_bf16 = (int)value;
+    else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "lin_waves") { if (value < 1 || value > 16) return fail("lin_waves must be 1..16"); c->lin_waves = (int)value; }
     else if (k == "stamps") c->stamp_on = (int)value;
     else if (k == "kstamp_sel") c->kstamp_sel = (int)value;

@@ -95,6 +95,82 @@ node_linear_kernel(NodeLinArgs a) {
     SM_STAMP(a.stamps, 2);
 }
 
+// The same product on the bf16 matrix cores with exactly split operands (gemm_bf16x6 arithmetic, sm_device.h):
+// the wave's weight block is resident as three bf16 piece fragments (12 KB per wave, host-split image
+//   wimg[(((ot * 3 + piece) * NB + b) * 64 + lane) * 4 + q], element order as in gemm_bf16x6),
+// the workgroup splits each activation tile once while staging it in LDS (one pair of float4 per thread)
+// and every wave reads ready-made B fragments: no vector work in the multiply loop at all.
+constexpr int kLin6Chunk = 8;     // column tiles staged at a time: 3 * H * 32 bytes each (12 KB at H = 128)
+
+template <int H>
+__global__ void __launch_bounds__(kNodeThreads)
+node_linear6_kernel(NodeLinArgs a) {
+    constexpr int NB = H / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lin6_lds[];
+    u32x4 *frag = reinterpret_cast<u32x4 *>(lin6_lds);              // [tile][piece][NB][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int nwave = blockDim.x >> 6;
+    const int ogroups = (a.n_out_tiles + nwave - 1) / nwave;
+    const int ot_raw = (blockIdx.x % ogroups) * nwave + wave;
+    const bool ot_ok = ot_raw < a.n_out_tiles;
+    const int ot = ot_ok ? ot_raw : a.n_out_tiles - 1;
+    const int ag = blockIdx.x / ogroups;
+    const int n_ct = (a.n_atoms + 15) / 16;
+    const int ct0 = ag * a.tiles_per_group, ct1 = min(ct0 + a.tiles_per_group, n_ct);
+
+    u32x4 w[3][NB];
+    {
+        const u32x4 *wi = reinterpret_cast<const u32x4 *>(a.wimg) + (size_t)ot * 3 * NB * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) w[p][b] = wi[(p * NB + b) * 64];
+    }
+
+    for (int cb = ct0; cb < ct1; cb += kLin6Chunk) {
+        const int nc = min(kLin6Chunk, ct1 - cb);
+        __syncthreads();                                            // previous chunk fully consumed
+        for (int idx = threadIdx.x; idx < nc * NB * 64; idx += blockDim.x) {
+            const int sl = idx & 63, sb = (idx >> 6) % NB, sc = idx / (64 * NB);
+            const int at = min((cb + sc) * 16 + (sl & 15), a.n_atoms - 1);
+            const float *src = a.in + (size_t)at * H + 32 * sb + 4 * (sl >> 4);
+            const float4 v0 = ldg4(src), v1 = ldg4(src + 16);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            u32x4 hi, mid, lo;
+            split3_bf16(v, hi, mid, lo);
+            u32x4 *dst = frag + ((size_t)(sc * 3) * NB + sb) * 64 + sl;
+            dst[0] = hi; dst[NB * 64] = mid; dst[2 * NB * 64] = lo;
+        }
+        __syncthreads();
+        for (int c = 0; c < nc; c += 2) {                           // two tiles at a time: independent MFMA chains
+            const bool two = c + 1 < nc;
+            const int atom0 = (cb + c) * 16 + n, atom1 = atom0 + 16;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (a.add_mol) {
+                const float4 t0 = ldg4(a.add_mol + (size_t)a.mol_of[min(atom0, a.n_atoms - 1)] * a.ld_add + 16 * ot + 4 * g);
+                const float4 t1 = ldg4(a.add_mol + (size_t)a.mol_of[min(atom1, a.n_atoms - 1)] * a.ld_add + 16 * ot + 4 * g);
+                acc0 = f32x4{t0.x, t0.y, t0.z, t0.w}; acc1 = f32x4{t1.x, t1.y, t1.z, t1.w};
+            }
+            const u32x4 *f0 = frag + (size_t)(c * 3) * NB * 64 + lane;
+            const u32x4 *f1 = frag + (size_t)((two ? c + 1 : c) * 3) * NB * 64 + lane;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const u32x4 h0 = f0[b * 64], m0 = f0[(NB + b) * 64], l0 = f0[(2 * NB + b) * 64];
+                const u32x4 h1 = f1[b * 64], m1 = f1[(NB + b) * 64], l1 = f1[(2 * NB + b) * 64];
+                acc0 = mfma_bf16(w[2][b], h0, acc0); acc1 = mfma_bf16(w[2][b], h1, acc1);      // smallest terms first
+                acc0 = mfma_bf16(w[1][b], m0, acc0); acc1 = mfma_bf16(w[1][b], m1, acc1);
+                acc0 = mfma_bf16(w[0][b], l0, acc0); acc1 = mfma_bf16(w[0][b], l1, acc1);
+                acc0 = mfma_bf16(w[1][b], h0, acc0); acc1 = mfma_bf16(w[1][b], h1, acc1);
+                acc0 = mfma_bf16(w[0][b], m0, acc0); acc1 = mfma_bf16(w[0][b], m1, acc1);
+                acc0 = mfma_bf16(w[0][b], h0, acc0); acc1 = mfma_bf16(w[0][b], h1, acc1);
+            }
+            if (ot_ok && atom0 < a.n_atoms) stg4(a.out + (size_t)atom0 * a.ld_out + 16 * ot + 4 * g, float4{acc0[0], acc0[1], acc0[2], acc0[3]});
+            if (ot_ok && two && atom1 < a.n_atoms) stg4(a.out + (size_t)atom1 * a.ld_out + 16 * ot + 4 * g, float4{acc1[0], acc1[1], acc1[2], acc1[3]});
+        }
+    }
+}
+
 struct NodeMlpArgs {
     const float *in0;      // [N][H]
     const float *in1;      // [N][H] second half of the input when K = 2H, else unused
