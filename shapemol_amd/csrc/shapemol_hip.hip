@@ -110,7 +110,7 @@ struct Image {
 };
 
 struct DevMlp { size_t w1, b1, g, be, w2, b2; };            // raw row-major (VALU kernels)
-struct DevMlpImg { size_t w1img, b1, g, be, w2img, b2; int nt2; };   // MFMA A-fragment images (sm_node.h)
+struct DevMlpImg { size_t w1img, b1, g, be, w2img, b2; int nt2; size_t w1img6, w2img6; };   // MFMA A-fragment images (sm_node.h)
 struct DevLayer {
     size_t pre_x2h, pre_h2x;          // images of [4H][H]: first-layer node blocks (k_i, k_j, v_i, v_j)
     size_t lin_img;                   // image of [8H][H]: pre_h2x of this layer followed by pre_x2h of the next
@@ -149,6 +149,8 @@ size_t put_padded(Image &im, const float *src, int n, int n_pad) {
     std::memcpy(&im.d[o], src, n * sizeof(float));
     return o;
 }
+void split3_host(float w, uint16_t (&p)[3]);
+size_t pack_linear6_image(Image &im, size_t src, int rows, int K);
 DevMlpImg put_mlp_img(Image &im, const Mlp &m) {
     DevMlpImg d;
     const int r2 = (m.l2.out + 15) / 16 * 16;
@@ -158,6 +160,8 @@ DevMlpImg put_mlp_img(Image &im, const Mlp &m) {
     d.w2img = pack_image(im, m.l2.w, m.l2.out, r2, m.l2.in, m.l2.in, 0);
     d.b2 = put_padded(im, m.l2.b, m.l2.out, r2);
     d.nt2 = r2 / 16;
+    d.w1img6 = pack_linear6_image(im, d.w1img, m.l1.out, m.l1.in);
+    d.w2img6 = pack_linear6_image(im, d.w2img, r2, m.l2.in);
     return d;
 }
 
@@ -346,7 +350,7 @@ struct shapemol_ctx {
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 16, edge_bf16 = 1, lin_bf16 = 1;
+    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 16, edge_bf16 = 1, lin_bf16 = 1, chain_bf16 = 1;
     int num_cu = 256;
     // profiling
     bool prof_on = false;
@@ -422,6 +426,7 @@ int set_edge_attr(int KP) {
 #define SETATTR3(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4));
+    HIPCHK(hipFuncSetAttribute((const void *)node_chain6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain6Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin6Chunk * 3 * H * 32));
     if (KP == 8) { SETATTR1(8) SETATTR2(8) SETATTR3(8) } else if (KP == 16) { SETATTR1(16) SETATTR2(16) SETATTR3(16) } else { SETATTR(32) }
 #undef SETATTR2
@@ -503,6 +508,7 @@ int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float 
 NodeFollow follow_of(const shapemol_ctx *c, const DevMlpImg &m, int mode, float *out, int ld_out, int n_store) {
     NodeFollow f{};
     f.w1img = c->P(m.w1img); f.b1 = c->P(m.b1); f.ln_g = c->P(m.g); f.ln_b = c->P(m.be);
+    f.w1img6 = c->P(m.w1img6); f.w2img6 = c->P(m.w2img6);
     f.w2img = c->P(m.w2img); f.b2 = c->P(m.b2); f.out = out; f.ld_out = ld_out; f.n_store = n_store; f.mode = mode; f.nt2 = m.nt2;
     return f;
 }
@@ -593,12 +599,14 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             na.stamps = (c->kstamp_sel == 3 && l == 0) ? c->kstamps : nullptr;
             na.w1img = c->P(Dl.no.w1img); na.b1 = c->P(Dl.no.b1); na.ln_g = c->P(Dl.no.g); na.ln_b = c->P(Dl.no.be);
             na.w2img = c->P(Dl.no.w2img); na.b2 = c->P(Dl.no.b2);
+            na.w1img6 = c->P(Dl.no.w1img6); na.w2img6 = c->P(Dl.no.w2img6);
             na.f[0] = follow_of(c, Dl.q_h2x, NODE_LN_RELU, c->q_h, H, H);
             na.n_follow = 1;
             if (has_next) { na.f[1] = follow_of(c, c->dm.layer[l + 1].q_x2h, NODE_LN_RELU, c->q_x, H, H); na.n_follow = 2; }
             else if (out_v) { na.f[1] = follow_of(c, c->dm.vhead, NODE_SSP, out_v, C, C); na.n_follow = 2; v_done = true; }
             const int n_ct = (n + 15) / 16;
-            LAUNCH("node_chain", hipLaunchKernelGGL(node_chain_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), 0, s, na));
+            if (c->chain_bf16) LAUNCH("node_chain", hipLaunchKernelGGL(node_chain6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain6Lds<H>::BYTES, s, na));
+            else LAUNCH("node_chain", hipLaunchKernelGGL(node_chain_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), 0, s, na));
             cur_h = dst;
             // per-node halves of the edge MLPs' first Linear: h2x of this layer | x2h of the next one
             if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->P(Dl.lin6_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
@@ -840,6 +848,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     if (k == "stop_layer") c->stop_layer = (int)value;
     else if (k == "edge_bf16") c->edge_bf16 = (int)value;
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
+    else if (k == "chain_bf16") c->chain_bf16 = (int)value;
     else if (k == "lin_waves") { if (value < 1 || value > 16) return fail("lin_waves must be 1..16"); c->lin_waves = (int)value; }
     else if (k == "stamps") c->stamp_on = (int)value;
     else if (k == "kstamp_sel") c->kstamp_sel = (int)value;

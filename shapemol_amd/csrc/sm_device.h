@@ -81,12 +81,12 @@ constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7 - i inside each 8-lane half row
 constexpr int DPP_ROW_MIRROR = 0x140;   // lane i <-> 15 - i inside each 16-lane row
 
-// all-reduce over the SEGW (8 or 16) consecutive lanes of a row segment
+// all-reduce over the SEGW (4, 8 or 16) consecutive lanes of a row segment
 template <int SEGW>
 SM_DEV float seg_sum(float v) {
     v += dpp_mov<DPP_XOR1>(v);
     v += dpp_mov<DPP_XOR2>(v);
-    v += dpp_mov<DPP_HALF_MIRROR>(v);
+    if constexpr (SEGW >= 8) v += dpp_mov<DPP_HALF_MIRROR>(v);
     if constexpr (SEGW == 16) v += dpp_mov<DPP_ROW_MIRROR>(v);
     return v;
 }
@@ -235,6 +235,19 @@ SM_DEV void split3_bf16(const float (&v)[8], u32x4 &hi, u32x4 &mid, u32x4 &lo) {
         mid[q] = pack_hi16(m0, m1);
         lo[q] = pack_hi16(__builtin_bit_cast(unsigned, s0), __builtin_bit_cast(unsigned, s1));
     }
+}
+
+// two floats -> one u32 (two bf16) per piece
+SM_DEV void split3_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+    const float r1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+    const unsigned m0 = __builtin_bit_cast(unsigned, r0), m1 = __builtin_bit_cast(unsigned, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, m0 & 0xFFFF0000u);
+    const float s1 = r1 - __builtin_bit_cast(float, m1 & 0xFFFF0000u);
+    hi = pack_hi16(u0, u1);
+    mid = pack_hi16(m0, m1);
+    lo = pack_hi16(__builtin_bit_cast(unsigned, s0), __builtin_bit_cast(unsigned, s1));
 }
 
 // acc[t2] += W2[16-row block t2] * act with the split weight image (LDS)

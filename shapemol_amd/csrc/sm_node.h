@@ -292,12 +292,14 @@ node_mlp2_kernel(NodeMlpArgs a) {
 // -------------------------------------------------------------------------------------------------
 struct NodeFollow {
     const float *w1img, *b1, *ln_g, *ln_b, *w2img, *b2;
+    const float *w1img6, *w2img6;                         // split bf16 images (node_chain6_kernel)
     float *out;
     int ld_out, n_store, mode, nt2;
 };
 struct NodeChainArgs {
     const float *att, *h;                                 // [N][H] each
     const float *w1img, *b1, *ln_g, *ln_b, *w2img, *b2;   // node_output MLP (K = 2H)
+    const float *w1img6, *w2img6;                         // split bf16 images (node_chain6_kernel)
     float *h_out;                                         // [N][H]
     NodeFollow f[2];
     int n_follow, n_atoms;
@@ -466,4 +468,219 @@ node_chain_kernel(NodeChainArgs a) {
         }
     }
     SM_TICK(a.stamps, 7);
+}
+
+// -------------------------------------------------------------------------------------------------
+// node_chain6_kernel: the same chain on the bf16 matrix cores with exactly split operands (the
+// gemm_bf16x6 arithmetic of sm_device.h).  Differences to node_chain_kernel:
+//   * every activation that feeds a Linear lives in LDS as ready-made B fragments (three bf16 pieces),
+//     written once by whoever produces it: the staging pass ([att | h]), the normalise pass (hidden
+//     tiles) or the producing wave itself (h': each lane owns half a fragment);
+//   * LayerNorm + ReLU (or shifted softplus) is no longer repeated by every wave of the team: the
+//     pre-activations cross LDS in fp32 and the team's lanes normalise disjoint slices (H / 8 lanes per
+//     column, two-pass statistics over a DPP row segment) -- one more barrier per MLP, ~8x less vector work;
+//   * weight blocks are resident per wave as 3 x K/32 fragments of 4 VGPRs, requested a stage ahead.
+// -------------------------------------------------------------------------------------------------
+template <int H>
+struct Chain6Lds {
+    static constexpr int NB = H / 32, CC = CHAIN_COLS;
+    static constexpr int FRAG = 3 * NB * CC * 64;          // u32x4 per fragment buffer of K = H
+    static constexpr int XS = H + 16;                      // fp32 pre-activation row stride
+    static constexpr int PRE = CC * 16 * XS;               // floats per pre-activation buffer
+    static constexpr size_t BYTES = (size_t)3 * FRAG * 16 + (size_t)2 * PRE * 4;
+};
+
+template <int H>
+__global__ void __launch_bounds__(H * 4)
+node_chain6_kernel(NodeChainArgs a) {
+    using L = Chain6Lds<H>;
+    constexpr int NT = H / 16, NB = H / 32, CC = CHAIN_COLS, XS = L::XS;
+    constexpr int LPC = NB * 4;                            // lanes per column in the normalise pass
+    static_assert(CC == 2, "the normalise pass covers exactly 32 columns");
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain6_lds[];
+    u32x4 *fin = reinterpret_cast<u32x4 *>(chain6_lds);    // [att | h] fragments (K = 2H); later the two hidden tiles
+    u32x4 *fhid0 = fin, *fhid1 = fin + L::FRAG;
+    u32x4 *fh = fin + 2 * L::FRAG;                         // fragments of the new h
+    float *pre0 = reinterpret_cast<float *>(fin + 3 * L::FRAG), *pre1 = pre0 + L::PRE;
+    const int lane = threadIdx.x & 63, ot = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int ct0 = blockIdx.x * CC;
+    const int f0 = 16 * ot + 4 * g;
+
+    auto load_w = [&](const float *img, auto &w) {         // w[3][KB]: this wave's block of a split image
+        constexpr int KB = sizeof(w[0]) / sizeof(u32x4);
+        const u32x4 *wi = reinterpret_cast<const u32x4 *>(img) + (size_t)ot * 3 * KB * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int b = 0; b < KB; ++b) w[p][b] = wi[(p * KB + b) * 64];
+    };
+    // acc[c] += W * X_c over KB k-steps; fragments at f[((piece * KB + b) * CC + c) * 64 + lane]
+    auto gemm6 = [&](const auto &w, const u32x4 *f, f32x4 (&acc)[CC]) {
+        constexpr int KB = sizeof(w[0]) / sizeof(u32x4);
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            u32x4 xh[CC], xm[CC], xl[CC];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                xh[c] = f[((0 * KB + b) * CC + c) * 64 + lane];
+                xm[c] = f[((1 * KB + b) * CC + c) * 64 + lane];
+                xl[c] = f[((2 * KB + b) * CC + c) * 64 + lane];
+            }
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[2][b], xh[c], acc[c]);      // smallest terms first
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[1][b], xm[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[0][b], xl[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[1][b], xh[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[0][b], xm[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[0][b], xh[c], acc[c]);
+        }
+    };
+    auto store_pre = [&](float *pre, const f32x4 (&acc)[CC]) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) stg4(pre + (c * 16 + n) * XS + f0, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
+    };
+    // activation of a pre-activation buffer -> fragments: LPC lanes per column, 8 features per lane
+    auto normalise = [&](const float *pre, int mode, const float *gam, const float *bet, u32x4 *fo) {
+        const int col = ot * (64 / LPC) + lane / LPC, ln = lane % LPC;
+        const int b = ln >> 2, gg = ln & 3;
+        const int fa = 32 * b + 4 * gg;
+        const float4 p0 = ldg4(pre + col * XS + fa), p1 = ldg4(pre + col * XS + fa + 16);
+        float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        if (mode == NODE_LN_RELU) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+            const float mean = seg_sum<LPC>(s) * (1.0f / H);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; q += d * d; }
+            const float var = seg_sum<LPC>(q) * (1.0f / H);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            const float4 g0 = ldg4(gam + fa), g1 = ldg4(gam + fa + 16), b0 = ldg4(bet + fa), b1 = ldg4(bet + fa + 16);
+            const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf((v[i] - mean) * rstd * ga[i] + be[i], 0.f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (v[i] > 20.f ? v[i] : log1pf(expf(v[i]))) - 0.6931471805599453f;
+        }
+        u32x4 hi, mid, lo;
+        split3_bf16(v, hi, mid, lo);
+        u32x4 *dst = fo + (b * CC + (col >> 4)) * 64 + gg * 16 + (col & 15);
+        dst[0] = hi; dst[NB * CC * 64] = mid; dst[2 * NB * CC * 64] = lo;
+    };
+    auto atom_of = [&](int c) { return min((ct0 + c) * 16 + n, a.n_atoms - 1); };
+    auto atom_ok = [&](int c) { return (ct0 + c) * 16 + n < a.n_atoms; };
+
+    // ---- stage 0: weights of the output MLP; [att | h] tiles -> fragments ----------------------------
+    u32x4 w1[3][2 * NB], w2[3][NB];
+    load_w(a.w1img6, w1);
+    for (int idx = threadIdx.x; idx < CC * 2 * NB * 64; idx += NT * 64) {
+        const int sl = idx & 63, sb = (idx >> 6) % (2 * NB), sc = idx / (64 * 2 * NB);
+        const int at = min((ct0 + sc) * 16 + (sl & 15), a.n_atoms - 1);
+        const float *src = (sb < NB ? a.att + (size_t)at * H + 32 * sb : a.h + (size_t)at * H + 32 * (sb - NB)) + 4 * (sl >> 4);
+        const float4 v0 = ldg4(src), v1 = ldg4(src + 16);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        u32x4 hi, mid, lo;
+        split3_bf16(v, hi, mid, lo);
+        u32x4 *dst = fin + (sb * CC + sc) * 64 + sl;
+        dst[0] = hi; dst[2 * NB * CC * 64] = mid; dst[2 * 2 * NB * CC * 64] = lo;
+    }
+    load_w(a.w2img6, w2);
+    float4 hres[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) hres[c] = ldg4(a.h + (size_t)atom_of(c) * H + f0);    // residual
+    const float4 b1 = ldg4(a.b1 + f0), b2 = ldg4(a.b2 + f0);
+    __syncthreads();
+
+    // ---- stage 1: h' = h + W2 relu(LN(W1 [att | h] + b1)) + b2 ---------------------------------------
+    {
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{b1.x, b1.y, b1.z, b1.w};
+        gemm6(w1, fin, acc);
+        store_pre(pre0, acc);
+    }
+    u32x4 wf0[3][NB], wf1[3][NB];                                    // first Linears of the follow-up MLPs
+    if (a.n_follow > 0) load_w(a.f[0].w1img6, wf0);
+    if (a.n_follow > 1) load_w(a.f[1].w1img6, wf1);
+    __syncthreads();
+    normalise(pre0, NODE_LN_RELU, a.ln_g, a.ln_b, fhid0);
+    __syncthreads();
+    {
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{b2.x, b2.y, b2.z, b2.w};
+        gemm6(w2, fhid0, acc);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const float4 hn = {acc[c][0] + hres[c].x, acc[c][1] + hres[c].y, acc[c][2] + hres[c].z, acc[c][3] + hres[c].w};
+            if (atom_ok(c)) stg4(a.h_out + (size_t)atom_of(c) * H + f0, hn);
+            // this lane's four features are half of fragment (k-step ot / 2, lane) of column tile c
+            unsigned ph[2], pm[2], pl[2];
+            split3_pair(hn.x, hn.y, ph[0], pm[0], pl[0]);
+            split3_pair(hn.z, hn.w, ph[1], pm[1], pl[1]);
+            uint2 *dst = reinterpret_cast<uint2 *>(fh + ((ot >> 1) * CC + c) * 64 + lane) + (ot & 1);
+            dst[0] = uint2{ph[0], ph[1]};
+            dst[NB * CC * 64 * 2] = uint2{pm[0], pm[1]};
+            dst[2 * NB * CC * 64 * 2] = uint2{pl[0], pl[1]};
+        }
+    }
+    if (a.n_follow == 0) return;
+    const bool on0 = ot < a.f[0].nt2, on1 = a.n_follow > 1 && ot < a.f[1].nt2;
+    u32x4 wg0[3][NB], wg1[3][NB];                                    // second Linears of the follow-up MLPs
+    if (on0) load_w(a.f[0].w2img6, wg0);
+    __syncthreads();
+
+    // ---- stage 2: follow-up MLPs on the new h ---------------------------------------------------------
+    {
+        const float4 ba = ldg4(a.f[0].b1 + f0);
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{ba.x, ba.y, ba.z, ba.w};
+        gemm6(wf0, fh, acc);
+        store_pre(pre0, acc);
+    }
+    if (a.n_follow > 1) {
+        const float4 bb = ldg4(a.f[1].b1 + f0);
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{bb.x, bb.y, bb.z, bb.w};
+        gemm6(wf1, fh, acc);
+        store_pre(pre1, acc);
+    }
+    if (on1) load_w(a.f[1].w2img6, wg1);
+    __syncthreads();
+    normalise(pre0, a.f[0].mode, a.f[0].ln_g, a.f[0].ln_b, fhid0);
+    if (a.n_follow > 1) normalise(pre1, a.f[1].mode, a.f[1].ln_g, a.f[1].ln_b, fhid1);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!(k == 0 ? on0 : on1)) continue;
+        const NodeFollow &F = a.f[k];
+        const float4 b = ldg4(F.b2 + f0);
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{b.x, b.y, b.z, b.w};
+        if (k == 0) gemm6(wg0, fhid0, acc); else gemm6(wg1, fhid1, acc);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            if (!atom_ok(c)) continue;
+            const int atom = atom_of(c);
+            if (f0 + 4 <= F.n_store && (F.ld_out & 3) == 0) {
+                stg4(F.out + (size_t)atom * F.ld_out + f0, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (f0 + r < F.n_store) F.out[(size_t)atom * F.ld_out + f0 + r] = acc[c][r];
+            }
+        }
+    }
 }
