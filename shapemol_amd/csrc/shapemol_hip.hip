@@ -214,14 +214,15 @@ template <int H>
 size_t pack_phase_image(Image &im, const Mlp &m, int kv_in, bool perm_heads) {
     constexpr int NT = H / 16, NB = NT / 2;
     const int nt2 = perm_heads ? 1 : NT;
-    const int o_wr = 0, o_g = o_wr + NT * 5 * 64, o_b = o_g + H, o_b2 = o_b + H, o_w2 = o_b2 + nt2 * 16;
+    const int G4 = (NT + 3) / 4;
+    const int o_wr = 0, o_g = o_wr + 5 * G4 * 256, o_b = o_g + H, o_b2 = o_b + H, o_w2 = o_b2 + nt2 * 16;
     const int total = o_w2 + 3 * nt2 * NB * 256;
     const size_t o = im.alloc(total);
     float *d = &im.d[o];
     for (int t = 0; t < NT; ++t)
         for (int s = 0; s < 5; ++s)
             for (int lane = 0; lane < 64; ++lane)
-                d[o_wr + (t * 5 + s) * 64 + lane] = m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * s + (lane >> 4)];
+                d[o_wr + ((s * G4 + t / 4) * 64 + lane) * 4 + (t & 3)] = m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * s + (lane >> 4)];
     std::memcpy(d + o_g, m.g, H * sizeof(float));
     std::memcpy(d + o_b, m.be, H * sizeof(float));
     for (int i = 0; i < nt2 * 16; ++i) {
@@ -578,7 +579,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         const bool phases = c->edge_bf16 && KP <= 16;
         if (phases && c->edge_bf16 == 1) {   // x2h attention, key and value phase in one launch
             EdgeFusedArgs fa{c->P(Dl.img_kx), c->P(Dl.img_vx), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew,
-                             c->alpha, c->att, n, l == 0 ? 4 * H : 8 * H};
+                             c->alpha, c->att, n, l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
             if (launch_fused<H, false>(c, s, fa)) return 1;
         } else if (phases) {   // x2h attention: key phase -> alpha, value phase -> att (separate launches)
             const float *pre = l == 0 ? c->pre0 : c->preAB + 4 * H;
@@ -613,7 +614,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                                  c->preAB, 8 * H, (has_next && l + 1 < L ? 8 : 4) * NT, n, nullptr)) return 1;
         }
         if (phases && c->edge_bf16 == 1) {   // h2x attention, both images resident in LDS
-            EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H};
+            EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H,
+                             (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
             if (launch_fused<H, true>(c, s, fa)) return 1;
         } else if (phases) {   // h2x attention (separate launches)
             EdgePhaseArgs pk{c->P(Dl.img_kh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, nullptr, n, 8 * H, 0, H};

@@ -164,16 +164,27 @@ SM_DEV void gemm_packed(const float *w, const float (&act)[NT * 4], f32x4 (&acc)
     }
 }
 
-// Gaussian smearing centres of the reference (models/common.py:19), coeff = -0.5/(mu1-mu0)^2 = -0.5
-__constant__ float c_rbf_centres[20] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
-                                        3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
+// e^x through v_exp_f32 (2^y, 1 ulp): relative error <= (|x| + 2) * 2^-24, enough for softmax terms and
+// Gaussian smearing (large |x| only where the value is negligible); ~3 instructions instead of ~12.
+SM_DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
-// B operand of the RBF product: lane group g supplies centre 4*s + g at k-step s (5 steps, G = 20)
-SM_DEV void rbf_dlayout(float d, int g, float (&rb)[5]) {
+// Gaussian smearing centres of the reference (models/common.py:19): 0, 1..3 step 0.25, 3.5..6 step 0.5, 7..10
+// step 1; coeff = -0.5/(mu1-mu0)^2 = -0.5.  Lane group g supplies centre 4*s + g at k-step s (5 steps, G = 20).
+// The five centres of a lane are computed arithmetically ONCE per kernel and kept in registers: indexing a
+// __constant__ table by lane costs a global load + full wait per centre inside the job loop.
+SM_DEV float rbf_centre(int i) {
+    return i == 0 ? 0.f : (i < 10 ? 1.f + 0.25f * (float)(i - 1) : (i < 16 ? 3.5f + 0.5f * (float)(i - 10) : 7.f + (float)(i - 16)));
+}
+SM_DEV void rbf_centres(int g, float (&cen)[5]) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) cen[s] = rbf_centre(4 * s + g);
+}
+// B operand of the RBF product
+SM_DEV void rbf_dlayout(float d, const float (&cen)[5], float (&rb)[5]) {
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-        const float u = d - c_rbf_centres[4 * s + g];
-        rb[s] = expf(-0.5f * (u * u));
+        const float u = d - cen[s];
+        rb[s] = fast_exp(-0.5f * (u * u));
     }
 }
 
@@ -280,4 +291,62 @@ SM_DEV void gemm_bf16x6(const unsigned *w, const float (&act)[NT * 4], f32x4 (&a
             acc[t2] = c;
         }
     }
+}
+
+// The same product one OUTPUT tile at a time (activations split once, up front), so that a tile's epilogue
+// (logits + softmax, weighted neighbour sums) is independent vector work that can issue under the next
+// tile's MFMAs instead of after all of them.
+template <int NT>
+SM_DEV void split_act(const float (&act)[NT * 4], u32x4 (&bh)[NT / 2], u32x4 (&bm)[NT / 2], u32x4 (&bl)[NT / 2]) {
+#pragma unroll
+    for (int b = 0; b < NT / 2; ++b) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act[8 * b + j];
+        split3_bf16(v, bh[b], bm[b], bl[b]);
+    }
+}
+template <int NT, int NT2>
+SM_DEV f32x4 tile_bf16x6(const unsigned *w, int t2, const u32x4 (&bh)[NT / 2], const u32x4 (&bm)[NT / 2],
+                         const u32x4 (&bl)[NT / 2], f32x4 c, int lane) {
+    constexpr int NB = NT / 2;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const u32x4 ah = *reinterpret_cast<const u32x4 *>(w + (((0 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+        const u32x4 am = *reinterpret_cast<const u32x4 *>(w + (((1 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+        const u32x4 al = *reinterpret_cast<const u32x4 *>(w + (((2 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+        c = mfma_bf16(al, bh[b], c);      // smallest terms first
+        c = mfma_bf16(am, bm[b], c);
+        c = mfma_bf16(ah, bl[b], c);
+        c = mfma_bf16(am, bh[b], c);
+        c = mfma_bf16(ah, bm[b], c);
+        c = mfma_bf16(ah, bh[b], c);
+    }
+    return c;
+}
+
+// Attention weights of one edge tile from its key rows (D layout) and the centre atoms' query rows:
+// logit of head 2t + (g >> 1) = (q . k over the head's 8 dims) / sqrt(8): 4 dims in this lane group and 4 in
+// the partner group g ^ 1.  One v_permlane16_swap pairs head blocks t and t + NT/2, so that afterwards the
+// even lane groups own the logits of blocks 0 .. NT/2-1 and the odd groups those of NT/2 .. NT-1 (no lane
+// repeats another's softmax); the softmax runs over the SEGW neighbour slots of the atom (a DPP row segment).
+// alpha[t] belongs to head block t + (NT/2) * (g & 1).
+template <int NT, int SEGW>
+SM_DEV float attention_weight_pair(float4 qa, float4 qb, f32x4 ka, f32x4 kb, bool ok) {
+    float pa = qa.x * ka[0] + qa.y * ka[1] + qa.z * ka[2] + qa.w * ka[3];
+    float pb = qb.x * kb[0] + qb.y * kb[1] + qb.z * kb[2] + qb.w * kb[3];
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(pa), "+v"(pb));
+    float p = pa + pb;
+    p = ok ? p * 0.35355339059327373f : -INFINITY;
+    const float mx = seg_max<SEGW>(p);
+    const float e = ok ? fast_exp(p - mx) : 0.f;
+    const float s = seg_sum<SEGW>(e);
+    return s > 0.f ? e * __builtin_amdgcn_rcpf(s) : 0.f;
+}
+template <int NT, int SEGW>
+SM_DEV void attention_weights(const float *qrow, const f32x4 (&k)[NT], bool ok, int g, float (&alpha)[NT / 2 > 0 ? NT / 2 : 1]) {
+    static_assert(NT % 2 == 0, "head blocks are paired");
+#pragma unroll
+    for (int t = 0; t < NT / 2; ++t)
+        alpha[t] = attention_weight_pair<NT, SEGW>(ldg4(qrow + 16 * t + 4 * g), ldg4(qrow + 16 * (t + NT / 2) + 4 * g), k[t], k[t + NT / 2], ok);
 }

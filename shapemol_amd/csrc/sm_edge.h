@@ -97,6 +97,8 @@ edge_attention_kernel(EdgeArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int n = lane & 15, g = lane >> 4;
+    float cen[5];
+    rbf_centres(g, cen);
     const int njobs = (a.n_atoms + APJ - 1) / APJ;
     const float inv_sqrt_dh = 0.35355339059327373f;   // 1/sqrt(8)
 
@@ -129,7 +131,7 @@ edge_attention_kernel(EdgeArgs a) {
             rel[tt][2] = xi2 - a.x[j * 3 + 2];
             const float d = sqrtf(rel[tt][0] * rel[tt][0] + rel[tt][1] * rel[tt][1] + rel[tt][2] * rel[tt][2]);
             float rb[5];
-            rbf_dlayout(d, g, rb);
+            rbf_dlayout(d, cen, rb);
             float hid[NT * 4];
             edge_hidden<NT>(pre_i, a.pre + (size_t)j * a.ld_pre + H, rb, lds + BL::K_WR, lds + BL::K_G,
                             lds + BL::K_B, lane, g, hid);
@@ -183,7 +185,7 @@ edge_attention_kernel(EdgeArgs a) {
             const int j = ok ? nb[tt] : atom;
             const float d = sqrtf(rel[tt][0] * rel[tt][0] + rel[tt][1] * rel[tt][1] + rel[tt][2] * rel[tt][2]);
             float rb[5];
-            rbf_dlayout(d, g, rb);
+            rbf_dlayout(d, cen, rb);
             float hid[NT * 4];
             edge_hidden<NT>(pre_i + 2 * H, a.pre + (size_t)j * a.ld_pre + 3 * H, rb, lds + BL::V_WR,
                             lds + BL::V_G, lds + BL::V_B, lane, g, hid);
@@ -310,6 +312,8 @@ edge_attention_t1_kernel(EdgeArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int n = lane & 15, g = lane >> 4;
+    float cen[5];
+    rbf_centres(g, cen);
     const int njobs = (a.n_atoms + APJ - 1) / APJ;
     const int jstride = gridDim.x * nwave;
     const float inv_sqrt_dh = 0.35355339059327373f;   // 1/sqrt(8)
@@ -355,7 +359,7 @@ edge_attention_t1_kernel(EdgeArgs a) {
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         const float d = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
         float rb[5];
-        rbf_dlayout(d, g, rb);
+        rbf_dlayout(d, cen, rb);
         // The key and value MLPs are independent until alpha * v, so the wave's instruction stream is laid
         // out to give every long MFMA run independent vector work to issue underneath it (waves of a SIMD
         // run the same phases in lockstep, so VALU-only stretches would otherwise leave the matrix pipe idle):

@@ -15,6 +15,12 @@
 // edge_attention_t1_kernel; loads of a job are issued before the weight image is copied to LDS.
 #pragma once
 #include "sm_device.h"
+#ifndef SM_ABLATE
+#define SM_ABLATE 0          // diagnostic builds only (build.sh --ablate MASK): compile-time mask of parts to drop
+#endif
+#ifndef SM_ABL
+#define SM_ABL(bit) (((SM_ABLATE) >> (bit)) & 1)
+#endif
 
 enum EdgePhase { PH_K = 0, PH_VX = 1, PH_VH = 2 };
 
@@ -34,13 +40,42 @@ struct EdgePhaseArgs {
 template <int H, int NT2>
 struct EdgePhaseImage {
     static constexpr int NT = H / 16, NB = NT / 2;
-    static constexpr int O_WR = 0;                      // [NT][5][64] fp32 A fragments of W1[:, 0:20]
-    static constexpr int O_G = O_WR + NT * 5 * 64;      // gamma[H]
+    static constexpr int G4 = (NT + 3) / 4;             // groups of four output tiles
+    static constexpr int O_WR = 0;                      // [5][G4][64][4] fp32 A fragments of W1[:, 0:20]: one 16-byte
+                                                        // LDS read feeds k-step s of tiles 4h .. 4h+3
+    static constexpr int O_G = O_WR + 5 * G4 * 256;     // gamma[H]
     static constexpr int O_B = O_G + H;                 // beta[H]
     static constexpr int O_B2 = O_B + H;                // b2[NT2 * 16]
     static constexpr int O_W2 = O_B2 + NT2 * 16;        // 3 pieces x [NT2][NB][64][4] u32 (two bf16 each)
     static constexpr int TOTAL = O_W2 + 3 * NT2 * NB * 256;
 };
+
+// acc[t] += W1[:, 0:20] rbf for all NT tiles (fp32 MFMA, K = 20 in five steps).  The A fragments of a k-step
+// are requested one step ahead: an MFMA that waits for an LDS read issued just before it pays the LDS latency
+// (~100+ cycles under load) instead of its 32 issue cycles.
+template <int NT>
+SM_DEV void first_linear_rbf(const float *wr, const float (&rb)[5], f32x4 (&acc)[NT], int lane) {
+    constexpr int G4 = (NT + 3) / 4;
+    float4 cur[G4], nxt[G4];
+#pragma unroll
+    for (int h = 0; h < G4; ++h) cur[h] = ldg4(wr + (h * 64 + lane) * 4);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        if (s + 1 < 5) {
+#pragma unroll
+            for (int h = 0; h < G4; ++h) nxt[h] = ldg4(wr + (((s + 1) * G4 + h) * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int h = 0; h < G4; ++h) {
+            const float w4[4] = {cur[h].x, cur[h].y, cur[h].z, cur[h].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * h + q < NT) acc[4 * h + q] = mfma16(w4[q], rb[s], acc[4 * h + q]);
+        }
+#pragma unroll
+        for (int h = 0; h < G4; ++h) cur[h] = nxt[h];
+    }
+}
 
 template <int H, int KP, int MODE>
 __global__ void __launch_bounds__(768)
@@ -54,9 +89,10 @@ edge_phase_kernel(EdgePhaseArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int n = lane & 15, g = lane >> 4;
+    float cen[5];
+    rbf_centres(g, cen);
     const int njobs = (a.n_atoms + APJ - 1) / APJ;
     const int jstride = gridDim.x * nwave;
-    const float inv_sqrt_dh = 0.35355339059327373f;   // 1/sqrt(8)
 
     int job = blockIdx.x * nwave + wave;
     bool have = job < njobs;
@@ -101,7 +137,7 @@ edge_phase_kernel(EdgePhaseArgs a) {
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         const float d = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
         float rb[5];
-        rbf_dlayout(d, g, rb);
+        rbf_dlayout(d, cen, rb);
         // first Linear (fp32 MFMA, K = 20) + LayerNorm + ReLU
         float hid[NT * 4];
         {
@@ -109,21 +145,12 @@ edge_phase_kernel(EdgePhaseArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma16(lds[IM::O_WR + (t * 5 + s) * 64 + lane], rb[s], acc[t]);
-            }
+            first_linear_rbf<NT>(lds + IM::O_WR, rb, acc, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
                 hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
             }
-        }
-        float4 qv[NT];
-        if constexpr (MODE == PH_K) {        // query row: in flight during LayerNorm + second Linear
-#pragma unroll
-            for (int t = 0; t < NT; ++t) qv[t] = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g);
         }
         ln_relu_dlayout<NT>(hid, lds + IM::O_G, lds + IM::O_B, g);
         // second Linear on the bf16 matrix cores (six exact piece products)
@@ -141,28 +168,15 @@ edge_phase_kernel(EdgePhaseArgs a) {
         job += jstride;
         have = job < njobs;
         if constexpr (MODE == PH_K) {
-            // logit of head 2t + (g >> 1): 4 dims here + 4 dims in the partner lane group (g ^ 1)
-            float alpha[NT];
+            f32x4 kk[NT2];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float p = qv[t].x * acc2[t][0] + qv[t].y * acc2[t][1] + qv[t].z * acc2[t][2] + qv[t].w * acc2[t][3];
-                p = sum_xor16(p);
-                p = cur_ok ? p * inv_sqrt_dh : -INFINITY;
-                const float mx = seg_max<SEGW>(p);
-                const float e = cur_ok ? expf(p - mx) : 0.f;
-                const float s = seg_sum<SEGW>(e);
-                alpha[t] = s > 0.f ? e / s : 0.f;
-            }
-            if (cur_atom_ok && (g & 1) == 0) {
-                float *ap = a.alpha + (size_t)cur_edge * 2 * NT + (g >> 1) * NT;
-                if constexpr (NT % 4 == 0) {
+            for (int t = 0; t < NT2; ++t) kk[t] = acc2[t];
+            float alpha[NT / 2];
+            if constexpr (NT2 == NT) attention_weights<NT, SEGW>(a.q + (size_t)cur_atom * H, kk, cur_ok, g, alpha);
+            if (cur_atom_ok) {
+                float *ap = a.alpha + (size_t)cur_edge * 2 * NT + (g >> 1) * NT + (NT / 2) * (g & 1);
 #pragma unroll
-                    for (int i = 0; i < NT / 4; ++i)
-                        stg4(ap + 4 * i, float4{alpha[4 * i], alpha[4 * i + 1], alpha[4 * i + 2], alpha[4 * i + 3]});
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) ap[t] = alpha[t];
-                }
+                for (int t = 0; t < NT / 2; ++t) ap[t] = alpha[t];
             }
             if (have) issue_loads(job);
         } else if constexpr (MODE == PH_VX) {
@@ -220,6 +234,7 @@ struct EdgeFusedArgs {
     float *alpha;           // [N*KP][2][NT] scratch
     float *out;             // x2h: [N][H]; h2x: [N][16][3]
     int n_atoms, ld_pre;
+    unsigned long long *stamps;   // diagnostic build only
 };
 
 template <int H, int KP, bool H2X>
@@ -236,10 +251,11 @@ edge_fused_kernel(EdgeFusedArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int n = lane & 15, g = lane >> 4;
+    float cen[5];
+    rbf_centres(g, cen);
     const int njobs = (a.n_atoms + APJ - 1) / APJ;
     const int jstride = gridDim.x * nwave;
     const int job0 = blockIdx.x * nwave + wave;
-    const float inv_sqrt_dh = 0.35355339059327373f;   // 1/sqrt(8)
 
     int atom = 0, jn = 0, edge = 0;
     bool atom_ok = false, ok = false;
@@ -261,16 +277,14 @@ edge_fused_kernel(EdgeFusedArgs a) {
         for (int t = 0; t < NT; ++t) { ga[t] = ldg4(pi + 16 * t + 4 * g); gb[t] = ldg4(pj + 16 * t + 4 * g); }
     };
     // hidden = ReLU(LN(A_i + B_j + W_r rbf)) with the image at `img`
-    auto hidden = [&](const float *img, const float (&rb)[5], float (&hid)[NT * 4]) {
+    auto hidden = [&](const float *img, const float (&rb)[5], float (&hid)[NT * 4], bool tick) {
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
-#pragma unroll
-        for (int s = 0; s < 5; ++s) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma16(img[IMK::O_WR + (t * 5 + s) * 64 + lane], rb[s], acc[t]);
-        }
+        if (tick) SM_TICK(a.stamps, 2);
+        first_linear_rbf<NT>(img + IMK::O_WR, rb, acc, lane);
+        if (tick) SM_TICK(a.stamps, 3);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
@@ -281,50 +295,64 @@ edge_fused_kernel(EdgeFusedArgs a) {
 
     int job = job0;
     bool have = job < njobs;
+    SM_TICK(a.stamps, 0);
     if (have) issue_loads(job, 0, H);
-    copy_to_lds(lds, a.image_k, IMK::TOTAL / 4, threadIdx.x, blockDim.x);
-    if constexpr (H2X) copy_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, threadIdx.x, blockDim.x);
+    if (!SM_ABL(8)) copy_to_lds(lds, a.image_k, IMK::TOTAL / 4, threadIdx.x, blockDim.x);
+    if constexpr (H2X) { if (!SM_ABL(9)) copy_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, threadIdx.x, blockDim.x); }
     __syncthreads();
+    SM_TICK(a.stamps, 1);
+    if (SM_ABL(10)) have = false;
 
     // ---- key phase ---------------------------------------------------------------------------------
     while (have) {
         asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         float rb[5];
-        rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), g, rb);
+        rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), cen, rb);
         float hid[NT * 4];
-        hidden(lds, rb, hid);
-        f32x4 kacc[NT];
+        hidden(lds, rb, hid, true);
+        SM_TICK(a.stamps, 4);
+        // second Linear one pair of head blocks (t, t + NT/2) at a time, software-pipelined: the logits and
+        // softmax of a finished pair are independent vector work placed under the next pair's MFMAs
+        float alpha[NT / 2];
+        {
+            u32x4 bh[NT / 2], bm[NT / 2], bl[NT / 2];
+            split_act<NT>(hid, bh, bm, bl);
+            SM_TICK(a.stamps, 5);
+            const unsigned *w2 = reinterpret_cast<const unsigned *>(lds) + IMK::O_W2;
+            auto pair_of = [&](int t, f32x4 &ka, f32x4 &kb) {
+                const float4 ba = ldg4(lds + IMK::O_B2 + 16 * t + 4 * g), bb = ldg4(lds + IMK::O_B2 + 16 * (t + NT / 2) + 4 * g);
+                ka = tile_bf16x6<NT, NT>(w2, t, bh, bm, bl, f32x4{ba.x, ba.y, ba.z, ba.w}, lane);
+                kb = tile_bf16x6<NT, NT>(w2, t + NT / 2, bh, bm, bl, f32x4{bb.x, bb.y, bb.z, bb.w}, lane);
+            };
+            const float *qrow = a.q + (size_t)atom * H + 4 * g;       // query rows (L2-hot), requested a pair ahead
+            float4 qa = ldg4(qrow), qb = ldg4(qrow + 16 * (NT / 2));
+            f32x4 ka, kb;
+            pair_of(0, ka, kb);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 b2 = ldg4(lds + IMK::O_B2 + 16 * t + 4 * g);
-            kacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
+            for (int t = 0; t < NT / 2; ++t) {
+                f32x4 na = ka, nb = kb;
+                float4 nqa = qa, nqb = qb;
+                if (t + 1 < NT / 2) {
+                    nqa = ldg4(qrow + 16 * (t + 1)); nqb = ldg4(qrow + 16 * (t + 1 + NT / 2));
+                    pair_of(t + 1, na, nb);
+                }
+                alpha[t] = attention_weight_pair<NT, SEGW>(qa, qb, ka, kb, ok);
+                ka = na; kb = nb; qa = nqa; qb = nqb;
+            }
         }
-        gemm_bf16x6<NT, NT>(reinterpret_cast<const unsigned *>(lds) + IMK::O_W2, hid, kacc, lane);
-        // logit of head 2t + (g >> 1): 4 dims here + 4 dims in the partner lane group (g ^ 1)
-        float alpha[NT];
+        if (atom_ok) {
+            float *ap = a.alpha + (size_t)edge * 2 * NT + (g >> 1) * NT + (NT / 2) * (g & 1);
+            if constexpr (NT % 8 == 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 qq = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g);     // L2/L1-hot, shared by the atom's lanes
-            float p = qq.x * kacc[t][0] + qq.y * kacc[t][1] + qq.z * kacc[t][2] + qq.w * kacc[t][3];
-            p = sum_xor16(p);
-            p = ok ? p * inv_sqrt_dh : -INFINITY;
-            const float mx = seg_max<SEGW>(p);
-            const float e = ok ? expf(p - mx) : 0.f;
-            const float s = seg_sum<SEGW>(e);
-            alpha[t] = s > 0.f ? e / s : 0.f;
-        }
-        if (atom_ok && (g & 1) == 0) {
-            float *ap = a.alpha + (size_t)edge * 2 * NT + (g >> 1) * NT;
-            if constexpr (NT % 4 == 0) {
-#pragma unroll
-                for (int i = 0; i < NT / 4; ++i)
+                for (int i = 0; i < NT / 8; ++i)
                     stg4(ap + 4 * i, float4{alpha[4 * i], alpha[4 * i + 1], alpha[4 * i + 2], alpha[4 * i + 3]});
             } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) ap[t] = alpha[t];
+                for (int t = 0; t < NT / 2; ++t) ap[t] = alpha[t];
             }
         }
+        SM_TICK(a.stamps, 6);
         job += jstride;
         have = job < njobs;
         asm volatile("" ::: "memory");       // keep the next job's loads below this job's tail (register pressure)
@@ -337,9 +365,11 @@ edge_fused_kernel(EdgeFusedArgs a) {
     if (have) issue_loads(job, 2 * H, 3 * H);
     __syncthreads();                         // key weights no longer needed; alpha stores of this wave drained
     if constexpr (!H2X) {
-        copy_to_lds(lds, a.image_v, IMV::TOTAL / 4, threadIdx.x, blockDim.x);
+        if (!SM_ABL(9)) copy_to_lds(lds, a.image_v, IMV::TOTAL / 4, threadIdx.x, blockDim.x);
         __syncthreads();
     }
+    SM_TICK(a.stamps, 7);
+    if (SM_ABL(11)) have = false;
 
     // ---- value phase -------------------------------------------------------------------------------
     const float *imv = lds + V_BASE;
@@ -347,7 +377,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
         asm volatile("" ::: "memory");
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         float rb[5];
-        rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), g, rb);
+        rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), cen, rb);
         const float w = ok ? a.ew[edge] : 0.f;
         const float *ap = a.alpha + (size_t)edge * 2 * NT + (g >> 1) * NT;
         float al[NT];
@@ -359,31 +389,31 @@ edge_fused_kernel(EdgeFusedArgs a) {
             for (int r = 0; r < NT; ++r) al[r] = r < NT / 2 ? ap[(NT / 2) * (g & 1) + r] : 0.f;
         }
         float hid[NT * 4];
-        hidden(imv, rb, hid);
-        f32x4 vacc[NT2V];
-#pragma unroll
-        for (int t = 0; t < NT2V; ++t) {
-            const float4 b2 = ldg4(imv + IMV::O_B2 + 16 * t + 4 * g);
-            vacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
-        }
-        gemm_bf16x6<NT, NT2V>(reinterpret_cast<const unsigned *>(imv) + IMV::O_W2, hid, vacc, lane);
+        hidden(imv, rb, hid, false);
+        u32x4 bh[NT / 2], bm[NT / 2], bl[NT / 2];
+        split_act<NT>(hid, bh, bm, bl);
+        const unsigned *w2v = reinterpret_cast<const unsigned *>(imv) + IMV::O_W2;
         const int cur_atom = atom;
         const bool store = atom_ok && (n % SEGW) == 0;
         if constexpr (!H2X) {
-            float o[NT * 4];
+            // one output tile at a time: the weighted neighbour sum of tile t issues under the MFMAs of tile t + 1
+            float *op = a.out + (size_t)cur_atom * H;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+                const float4 b2 = ldg4(imv + IMV::O_B2 + 16 * t + 4 * g);
+                const f32x4 v = tile_bf16x6<NT, NT>(w2v, t, bh, bm, bl, f32x4{b2.x, b2.y, b2.z, b2.w}, lane);
                 const float aw = al[t] * w;
+                float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[4 * t + r] = seg_sum<SEGW>(aw * vacc[t][r]);
-            }
-            if (store) {
-                float *op = a.out + (size_t)cur_atom * H;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    stg4(op + 16 * t + 4 * g, float4{o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]});
+                for (int r = 0; r < 4; ++r) o[r] = seg_sum<SEGW>(aw * v[r]);
+                if (store) stg4(op + 16 * t + 4 * g, float4{o[0], o[1], o[2], o[3]});
             }
         } else {
+            f32x4 vacc[1];
+            {
+                const float4 b2 = ldg4(imv + IMV::O_B2 + 4 * g);
+                vacc[0] = tile_bf16x6<NT, 1>(w2v, 0, bh, bm, bl, f32x4{b2.x, b2.y, b2.z, b2.w}, lane);
+            }
             // value row 4g + r belongs to head 2*((NT/2)*(g&1) + r) + (g>>1); rows with r >= NT/2 are padding
             float o[12];
 #pragma unroll

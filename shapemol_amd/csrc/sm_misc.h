@@ -229,6 +229,8 @@ __global__ void __launch_bounds__(256)
 edge_weight_kernel(EdgeWeightArgs a) {
     constexpr int NT = H / 16;
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    float cen[5];
+    rbf_centres(g, cen);
     const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int e_raw = tile * 16 + n;
     if (tile * 16 >= a.n_slots) return;
@@ -240,7 +242,7 @@ edge_weight_kernel(EdgeWeightArgs a) {
     const int j = ok ? jraw : i;
     const float r0 = a.x[i * 3] - a.x[j * 3], r1 = a.x[i * 3 + 1] - a.x[j * 3 + 1], r2 = a.x[i * 3 + 2] - a.x[j * 3 + 2];
     float rb[5];
-    rbf_dlayout(sqrtf(r0 * r0 + r1 * r1 + r2 * r2), g, rb);
+    rbf_dlayout(sqrtf(r0 * r0 + r1 * r1 + r2 * r2), cen, rb);
     float hid[NT * 4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from shapemol_amd import ScorePosNet3D, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--sel", type=int, default=1); ap.add_argument("--batch", type=int, default=256)
-ap.add_argument("--waves", type=int, default=8)
+ap.add_argument("--waves", type=int, default=12)
 a = ap.parse_args()
 cfg = yaml.safe_load(open(os.path.join(ROOT, "config/training/dgcnn_signeddist_512_attention_residue_uniform_pos0_10_pos1.e-7_0.01_6_v001.yml")))["model"]
 m = ScorePosNet3D(cfg, 15); m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(cfg, 7).items()}); m = m.to("cuda:0")
@@ -25,7 +25,8 @@ st = st[st[:, 0] > 0]
 t0 = st[:, 0].min()
 print(f"waves stamped: {len(st)}; all times in us relative to the earliest stamp 0")
 names = {0: ["start", "weights+tile0 loaded", "all tiles done (stores drained)", "-", "-", "-", "-", "-"],
-         1: ["start", "weights in LDS", "k hidden (gather+GEMM1+LN)", "k GEMM2", "logits+softmax", "v hidden", "v GEMM2", "reduce+store (job 1)"]}
+         1: ["start", "K image in LDS (barrier 1)", "key: rbf + gathered rows summed", "key: GEMM1 (fp32 MFMA)", "key: LayerNorm+ReLU", "key: split", "key: GEMM2+softmax+alpha stores issued", "V image swapped (2 barriers)"]}
+names[2] = names[1]
 names[3] = ["start", "stage1 GEMM1 issued (+W2 loads)", "after barrier 1", "h' computed+stored", "after barrier 2", "follow GEMM1s issued", "after barrier 3", "end"]
 nm = names[a.sel if a.sel in names else 1]
 for k in range(8):
