@@ -111,7 +111,11 @@ int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, co
  *          "edge_bf16"  (1 = fused key/value edge kernel with exactly split bf16 second Linears [default],
  *                        2 = the same arithmetic as separate key / value launches, 0 = fp32-MFMA edge kernels;
  *                        k > 16 always uses the fp32 kernels),
- *          "edge_waves" (1..12 waves per workgroup of the edge kernels, tuning),
+ *          "lin_bf16", "chain_bf16" (1 = node kernels on the bf16 matrix cores with exactly split operands
+ *                        [default], 0 = fp32-MFMA node kernels),
+ *          "vn_fuse"    (1 = coordinate update fused behind the h2x attention with an in-kernel grid barrier,
+ *                        0 = separate vn_stats / vn_apply launches [default: measured equal in graph replay]),
+ *          "edge_waves" (waves per workgroup of the edge kernels, 1..12; 0 = automatic: ceil(jobs / CUs) [default]),
  *          "lin_waves"  (1..16 waves per workgroup of node_linear_kernel, tuning),
  *          "stamps", "kstamp_sel" (clock-stamp diagnostics; only meaningful in the --stamps build).
  * Changing an option invalidates a captured graph (the next _sample re-captures). */

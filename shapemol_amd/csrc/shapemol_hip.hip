@@ -351,7 +351,7 @@ struct shapemol_ctx {
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = kEdgeThreadsDefault, lin_waves = 16, edge_bf16 = 1, lin_bf16 = 1, chain_bf16 = 1;
+    int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 1, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 0;
     int num_cu = 256;
     // profiling
     bool prof_on = false;
@@ -405,7 +405,7 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
         A(&c->h_a, capN * H) || A(&c->h_b, capN * H) || A(&c->pre0, capN * 4 * H) || A(&c->preAB, capN * 8 * H) || A(&c->q_x, capN * H) || A(&c->q_h, capN * H) ||
         A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->alpha, capN * c->KP * 2 * (H / 16)) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
         A(&c->x_b, capN * 3) || A(&c->x_state, capN * 3) || A(&c->pred_pos, capN * 3) ||
-        A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * kBnReplicas * 2 * hd))
+        A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * kBnReplicas * 2 * hd + L + 1))
         return 1;
     c->capN = capN; c->capB = capB;
     return 0;
@@ -426,7 +426,7 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_VH>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, 1>::TOTAL * 4));
 #define SETATTR3(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4));
+    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4 + 12 * 512));
     HIPCHK(hipFuncSetAttribute((const void *)node_chain6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain6Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin6Chunk * 3 * H * 32));
     if (KP == 8) { SETATTR1(8) SETATTR2(8) SETATTR3(8) } else if (KP == 16) { SETATTR1(16) SETATTR2(16) SETATTR3(16) } else { SETATTR(32) }
@@ -437,42 +437,50 @@ int set_edge_attr(int KP) {
     return 0;
 }
 
+// Waves per workgroup of the single-tile edge kernels: one job per wave while the jobs fit (the launch then lasts
+// one job latency), on as many CUs as possible: ceil(jobs / CUs) waves, at least 4 and at most 12 (the 168-VGPR budget).
+static int edge_waves_for(const shapemol_ctx *c, int njobs) {
+    if (c->edge_threads > 0) return c->edge_threads / 64;
+    return std::max(4, std::min(12, (njobs + c->num_cu - 1) / c->num_cu));
+}
+
 template <int H, bool H2X>
 int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {
     const int KP = c->KP;
     const int apj = KP >= 16 ? 1 : 16 / KP;
     const int njobs = (a.n_atoms + apj - 1) / apj;
-    const int waves = c->edge_threads / 64;
+    const int waves = KP <= 16 ? edge_waves_for(c, njobs) : (c->edge_threads > 0 ? c->edge_threads / 64 : 12);
     const int grid = KP <= 16 ? std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves))
                               : std::max(1, std::min(c->num_cu, njobs));
     const size_t shm = EdgeBlob<H, H2X>::TOTAL * sizeof(float);
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
-    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 8, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
-    else if (KP == 16) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 16, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
-    else LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else if (KP == 16) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     return 0;
 }
 
 template <int H, int MODE>
 int launch_phase(shapemol_ctx *c, hipStream_t s, const char *nm, const EdgePhaseArgs &a) {
     const int KP = c->KP, apj = 16 / KP;
-    const int njobs = (a.n_atoms + apj - 1) / apj, waves = c->edge_threads / 64;
+    const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
     const size_t shm = EdgePhaseImage<H, (MODE == PH_VH ? 1 : H / 16)>::TOTAL * sizeof(float);
-    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_phase_kernel<H, 8, MODE>), dim3(grid), dim3(c->edge_threads), shm, s, a));
-    else LAUNCH(nm, hipLaunchKernelGGL((edge_phase_kernel<H, 16, MODE>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_phase_kernel<H, 8, MODE>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else LAUNCH(nm, hipLaunchKernelGGL((edge_phase_kernel<H, 16, MODE>), dim3(grid), dim3(waves * 64), shm, s, a));
     return 0;
 }
 
 template <int H, bool H2X>
 int launch_fused(shapemol_ctx *c, hipStream_t s, const EdgeFusedArgs &a) {
     const int KP = c->KP, apj = 16 / KP;
-    const int njobs = (a.n_atoms + apj - 1) / apj, waves = c->edge_threads / 64;
+    const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
-    const size_t shm = (EdgePhaseImage<H, H / 16>::TOTAL + (H2X ? EdgePhaseImage<H, 1>::TOTAL : 0)) * sizeof(float);
+    const size_t shm = (EdgePhaseImage<H, H / 16>::TOTAL + (H2X ? EdgePhaseImage<H, 1>::TOTAL : 0)) * sizeof(float)
+                       + (H2X ? (size_t)waves * 32 * 2 * 8 : 0);   // + reduction scratch of the fused coordinate update
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
-    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 8, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
-    else LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 16, H2X>), dim3(grid), dim3(c->edge_threads), shm, s, a));
+    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     return 0;
 }
 
@@ -553,7 +561,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     const int L = g.num_layers, hd = g.n_heads, C = g.num_classes, D = g.time_emb_dim, KP = c->KP;
     const int n = (int)N;
     AtomEmbArgs ae{c->P(c->dm.embw), c->P(c->dm.embb), v_in, c->mol_of, c->ttab, c->t_mol, sampling ? c->steps : nullptr,
-                   c->steps + 1, c->bn_acc, c->h_a, n, H, C, D, t_first, L * kBnReplicas * 2 * hd};
+                   c->steps + 1, c->bn_acc, c->h_a, n, H, C, D, t_first, L * kBnReplicas * 2 * hd + L};   // + the grid-barrier counters
     LAUNCH("embed", hipLaunchKernelGGL(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
     LAUNCH("knn", hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x_in, c->mol_of, c->mol_off, n, g.knn, KP, c->nbr));
     EdgeWeightArgs ea{x_in, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
@@ -613,9 +621,18 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->P(Dl.lin6_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
                                  c->preAB, 8 * H, (has_next && l + 1 < L ? 8 : 4) * NT, n, nullptr)) return 1;
         }
+        float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
+        bool vn_done = false;
         if (phases && c->edge_bf16 == 1) {   // h2x attention, both images resident in LDS
             EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H,
                              (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
+            if (c->vn_fuse) {   // coordinate update behind the attention, in the same launch (grid barrier inside)
+                double *tail = c->bn_acc + (size_t)L * kBnReplicas * 2 * hd;
+                fa.vn = {c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o), c->P(Dl.wd_o),
+                         c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd,
+                         reinterpret_cast<unsigned *>(tail + l), reinterpret_cast<int *>(tail + L), x_next, 1};
+                vn_done = true;
+            }
             if (launch_fused<H, true>(c, s, fa)) return 1;
         } else if (phases) {   // h2x attention (separate launches)
             EdgePhaseArgs pk{c->P(Dl.img_kh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, nullptr, n, 8 * H, 0, H};
@@ -627,12 +644,13 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                        (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
             if (launch_edge<H, true>(c, s, e)) return 1;
         }
-        float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
         VnArgs va{cur_x, c->o3, c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o),
                   c->P(Dl.wd_o), c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, x_next, n, hd};
         const int per_blk = 256 / hd;
-        LAUNCH("vn_stats", hipLaunchKernelGGL(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(kVnThreads), 0, s, va));
-        LAUNCH("vn_apply", hipLaunchKernelGGL(vn_apply_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
+        if (!vn_done) {
+            LAUNCH("vn_stats", hipLaunchKernelGGL(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(kVnThreads), 0, s, va));
+            LAUNCH("vn_apply", hipLaunchKernelGGL(vn_apply_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
+        }
         cur_x = x_next;
     }
     c->last_h = cur_h; c->last_x = cur_x;
@@ -851,10 +869,11 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     else if (k == "edge_bf16") c->edge_bf16 = (int)value;
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "chain_bf16") c->chain_bf16 = (int)value;
+    else if (k == "vn_fuse") c->vn_fuse = (int)value;
     else if (k == "lin_waves") { if (value < 1 || value > 16) return fail("lin_waves must be 1..16"); c->lin_waves = (int)value; }
     else if (k == "stamps") c->stamp_on = (int)value;
     else if (k == "kstamp_sel") c->kstamp_sel = (int)value;
-    else if (k == "edge_waves") { if (value < 1 || value > 12) return fail("edge_waves must be 1..12"); c->edge_threads = (int)value * 64; }
+    else if (k == "edge_waves") { if (value < 0 || value > 12) return fail("edge_waves must be 0 (automatic) .. 12"); c->edge_threads = (int)value * 64; }   // 0 = automatic
     else return fail("unknown option " + k);
     if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
     return 0;
@@ -878,6 +897,7 @@ int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t
     else if (k == "o3") { src = c->o3; bytes = N * 48 * 4; }
     else if (k == "stamps") { src = c->stamps; bytes = 2048 * 8; }
     else if (k == "kstamps") { src = c->kstamps; bytes = (size_t)8 * 16 * 4096 * 8; }
+    else if (k == "vn_err") { src = c->bn_acc + (size_t)g.num_layers * kBnReplicas * 2 * g.n_heads + g.num_layers; bytes = 4; }
     else if (k == "bnstat") { src = c->bn_acc; bytes = (size_t)g.num_layers * kBnReplicas * 2 * g.n_heads * 8; }
     else { fail("shapemol_debug_read: unknown buffer " + k); return -1; }
     if (!src || bytes > max_bytes) { fail("shapemol_debug_read: buffer unavailable or destination too small"); return -1; }

@@ -235,7 +235,24 @@ struct EdgeFusedArgs {
     float *out;             // x2h: [N][H]; h2x: [N][16][3]
     int n_atoms, ld_pre;
     unsigned long long *stamps;   // diagnostic build only
+    // h2x only: the coordinate update that follows the attention (VN-linear + train-mode batch-norm + VN-leaky-ReLU,
+    // shape_vn_layers.py:41-61,95-110; uni_transformer.py:153-162) fused behind it.  enable = 0 leaves it to
+    // vn_stats_kernel / vn_apply_kernel (sm_misc.h), whose arithmetic this follows line by line.
+    struct VnFuse {
+        const float *ps;            // [B][2][heads][3]
+        const float *wf_x, *wd_x;   // [heads]
+        const float *wf_o, *wd_o;   // [heads][16]
+        const float *bn_g, *bn_b;   // [heads]
+        const int *mol_of;
+        float *pd;                  // [N][heads][6]
+        double *acc;                // [kVnReplicas][2][heads], zeroed at the start of the evaluation
+        unsigned *arrive;           // grid-barrier counter of this launch, zeroed likewise
+        int *err;                   // set to 1 if the grid barrier timed out (workgroups not co-resident)
+        float *x_out;               // [N][3]
+        int enable;
+    } vn;
 };
+constexpr int kVnReplicas = 16;
 
 template <int H, int KP, bool H2X>
 __global__ void __launch_bounds__(768)
@@ -373,6 +390,12 @@ edge_fused_kernel(EdgeFusedArgs a) {
 
     // ---- value phase -------------------------------------------------------------------------------
     const float *imv = lds + V_BASE;
+    constexpr int HD = H / 8;                                     // heads = VN channels
+    // fused coordinate update (h2x): lane = (atom of the job, channel)
+    double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);   // [nwave][32][2] behind the images
+    const int v_al = lane >> 4, v_c = lane & 15;
+    const bool v_lane = H2X && v_al < APJ && v_c < HD;
+    double v_s1 = 0.0, v_s2 = 0.0;
     while (have) {
         asm volatile("" ::: "memory");
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
@@ -433,5 +456,133 @@ edge_fused_kernel(EdgeFusedArgs a) {
         have = job < njobs;
         asm volatile("" ::: "memory");
         if (have) issue_loads(job, 2 * H, 3 * H);
+    }
+
+    if constexpr (H2X) {
+        if (!a.vn.enable) return;
+        // ---- VN-linear of this wave's atoms: p, d per channel from the 16 attention rows (+ x, + shape term);
+        //      lane = (atom of the job, channel).  The rows were stored by this wave above (same CU, write-through).
+        __syncthreads();
+        for (int jb = job0; jb < njobs; jb += jstride) {
+            const int va = jb * APJ + v_al;
+            if (v_lane && va < a.n_atoms) {
+                const float *ov = a.out + (size_t)va * 48;
+                float orow[48];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const float4 t = ldg4(ov + 4 * i);
+                    orow[4 * i] = t.x; orow[4 * i + 1] = t.y; orow[4 * i + 2] = t.z; orow[4 * i + 3] = t.w;
+                }
+                float wf[16], wd[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 t = ldg4(a.vn.wf_o + v_c * 16 + 4 * i), u = ldg4(a.vn.wd_o + v_c * 16 + 4 * i);
+                    wf[4 * i] = t.x; wf[4 * i + 1] = t.y; wf[4 * i + 2] = t.z; wf[4 * i + 3] = t.w;
+                    wd[4 * i] = u.x; wd[4 * i + 1] = u.y; wd[4 * i + 2] = u.z; wd[4 * i + 3] = u.w;
+                }
+                const float *psf = a.vn.ps + ((size_t)a.vn.mol_of[va] * 2 * HD + v_c) * 3;
+                const float *psd = psf + HD * 3;
+                const float wfx = a.vn.wf_x[v_c], wdx = a.vn.wd_x[v_c];
+                float p[3], d[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float xk = a.x[va * 3 + k];
+                    float pp = wfx * xk, dd = wdx * xk;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        pp += wf[r] * orow[r * 3 + k];
+                        dd += wd[r] * orow[r * 3 + k];
+                    }
+                    p[k] = pp + psf[k];
+                    d[k] = dd + psd[k];
+                }
+                float *out = a.vn.pd + ((size_t)va * HD + v_c) * 6;
+                out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
+                const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
+                v_s1 += (double)nrm;
+                v_s2 += (double)nrm * (double)nrm;
+            }
+        }
+        // ---- batch statistics of ||p|| over ALL atoms of the batch: workgroup sums -> replicated double atomics ----
+        if (lane < 32) { vn_red[(wave * 32 + lane) * 2] = v_s1; vn_red[(wave * 32 + lane) * 2 + 1] = v_s2; }
+        __syncthreads();
+        if (threadIdx.x < HD) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int w = 0; w < nwave; ++w)
+                for (int al = 0; al < APJ; ++al) {
+                    s1 += vn_red[(w * 32 + al * 16 + threadIdx.x) * 2];
+                    s2 += vn_red[(w * 32 + al * 16 + threadIdx.x) * 2 + 1];
+                }
+            double *acc = a.vn.acc + (size_t)(blockIdx.x % kVnReplicas) * 2 * HD;
+            atomicAdd(acc + threadIdx.x, s1);
+            atomicAdd(acc + HD + threadIdx.x, s2);
+        }
+        // ---- grid barrier: every workgroup is resident (grid <= CUs, one workgroup per CU), so arrival
+        //      counting cannot deadlock; a bounded wait turns a violated assumption into an error flag.
+        //      Only device-scope atomics cross workgroups here (the sums and the counter): no cache fence is
+        //      needed, just the order "sums acknowledged (vmcnt drained by the barrier) -> arrive". ----
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(a.vn.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(a.vn.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > 4000000) { *a.vn.err = 1; break; }
+            }
+        }
+        __syncthreads();
+        double *stat = vn_red;                                    // [2][HD] totals, behind the staged replicas
+        for (int i = threadIdx.x; i < kVnReplicas * 2 * HD; i += blockDim.x)      // one coherent load per thread
+            vn_red[2 * HD + i] = __hip_atomic_load(a.vn.acc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (threadIdx.x < 2 * HD) {
+            double t = 0.0;
+            for (int r = 0; r < kVnReplicas; ++r) t += vn_red[2 * HD + r * 2 * HD + threadIdx.x];
+            stat[threadIdx.x] = t;
+        }
+        __syncthreads();
+        // ---- normalise, VN-leaky-ReLU, mean over channels, x update (vn_apply_kernel) -------------------
+        float meanf = 0.f, rstd = 0.f, bng = 0.f, bnb = 0.f;
+        if (v_lane) {
+            const double cnt = (double)a.n_atoms;
+            const double mean = stat[v_c] / cnt;
+            double var = stat[HD + v_c] / cnt - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            meanf = (float)mean;
+            rstd = 1.0f / sqrtf((float)var + 1e-5f);
+            bng = a.vn.bn_g[v_c]; bnb = a.vn.bn_b[v_c];
+        }
+        for (int jb = job0; jb < njobs; jb += jstride) {
+            const int va = jb * APJ + v_al;
+            const bool on = v_lane && va < a.n_atoms;
+            float o[3] = {0.f, 0.f, 0.f};
+            if (on) {
+                const float *pd = a.vn.pd + ((size_t)va * HD + v_c) * 6;
+                float p[3] = {pd[0], pd[1], pd[2]};
+                const float d[3] = {pd[3], pd[4], pd[5]};
+                const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
+                const float nbn = (nrm - meanf) * rstd * bng + bnb;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) p[k] = p[k] / nrm * nbn;
+                const float dot = p[0] * d[0] + p[1] * d[1] + p[2] * d[2];
+                const float dsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                const float coef = dot / (dsq + 1e-6f);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float neg = p[k] - coef * d[k];
+                    o[k] = 0.2f * p[k] + 0.8f * (dot >= 0.f ? p[k] : neg);
+                }
+            }
+            float res[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) res[k] = seg_sum<HD>(o[k]);           // over the channels of the atom
+            if (on && v_c < 3) {
+                const float r = v_c == 0 ? res[0] : (v_c == 1 ? res[1] : res[2]);
+                const float *ob = a.out + (size_t)va * 48;
+                float att = 0.f;
+                for (int rr = 0; rr < 16; ++rr) att += ob[rr * 3 + v_c];       // padding rows are zero
+                a.vn.x_out[va * 3 + v_c] = a.x[va * 3 + v_c] + (att / HD + r / HD);
+            }
+        }
     }
 }

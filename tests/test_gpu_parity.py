@@ -70,6 +70,28 @@ def test_forward_b4_golden(name):
         assert maxabs(out[k], f[f"{name}_{k}"]) < FWD_TOL, k
 
 
+@pytest.mark.parametrize("opts", [{"edge_bf16": 0}, {"edge_bf16": 2}, {"lin_bf16": 0, "chain_bf16": 0}, {"vn_fuse": 1}],
+                         ids=["edge_fp32", "edge_phases", "node_fp32", "vn_fused"])
+def test_forward_alternative_kernels_golden(opts):
+    """The optional kernel variants behind shapemol_set_option compute the same forward (ragged batch too)."""
+    m = hip_model()
+    try:
+        for k, v in opts.items():
+            m.set_option(k, v)
+        f = golden("forward_b4.npz")
+        out = run_forward(m, f, "t500_t")
+        for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+            assert maxabs(out[k], f[f"t500_{k}"]) < FWD_TOL, k
+        f = golden("forward_ragged.npz")
+        out = run_forward(m, f, "t")
+        for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+            assert maxabs(out[k], f[k]) < FWD_TOL, k
+        assert int(m.debug_read("vn_err", (1,), np.int32)[0]) == 0
+    finally:
+        for k in opts:
+            m.set_option(k, {"edge_bf16": 1, "lin_bf16": 1, "chain_bf16": 1, "vn_fuse": 0}[k])
+
+
 def test_forward_ragged_golden():
     """1-, 2-, 5-atom molecules: fewer than k neighbours / none at all."""
     m = hip_model()

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from shapemol_amd import ScorePosNet3D, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--sel", type=int, default=1); ap.add_argument("--batch", type=int, default=256)
-ap.add_argument("--waves", type=int, default=12)
+ap.add_argument("--waves", type=int, default=0)
 a = ap.parse_args()
 cfg = yaml.safe_load(open(os.path.join(ROOT, "config/training/dgcnn_signeddist_512_attention_residue_uniform_pos0_10_pos1.e-7_0.01_6_v001.yml")))["model"]
 m = ScorePosNet3D(cfg, 15); m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(cfg, 7).items()}); m = m.to("cuda:0")
