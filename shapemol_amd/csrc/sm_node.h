@@ -579,6 +579,7 @@ node_chain6_kernel(NodeChainArgs a) {
     auto atom_of = [&](int c) { return min((ct0 + c) * 16 + n, a.n_atoms - 1); };
     auto atom_ok = [&](int c) { return (ct0 + c) * 16 + n < a.n_atoms; };
 
+    SM_TICK(a.stamps, 0);
     // ---- stage 0: weights of the output MLP; [att | h] tiles -> fragments ----------------------------
     u32x4 w1[3][2 * NB], w2[3][NB];
     load_w(a.w1img6, w1);
@@ -599,6 +600,7 @@ node_chain6_kernel(NodeChainArgs a) {
     for (int c = 0; c < CC; ++c) hres[c] = ldg4(a.h + (size_t)atom_of(c) * H + f0);    // residual
     const float4 b1 = ldg4(a.b1 + f0), b2 = ldg4(a.b2 + f0);
     __syncthreads();
+    SM_TICK(a.stamps, 1);
 
     // ---- stage 1: h' = h + W2 relu(LN(W1 [att | h] + b1)) + b2 ---------------------------------------
     {
@@ -612,8 +614,10 @@ node_chain6_kernel(NodeChainArgs a) {
     if (a.n_follow > 0) load_w(a.f[0].w1img6, wf0);
     if (a.n_follow > 1) load_w(a.f[1].w1img6, wf1);
     __syncthreads();
+    SM_TICK(a.stamps, 2);
     normalise(pre0, NODE_LN_RELU, a.ln_g, a.ln_b, fhid0);
     __syncthreads();
+    SM_TICK(a.stamps, 3);
     {
         f32x4 acc[CC];
 #pragma unroll
@@ -638,6 +642,7 @@ node_chain6_kernel(NodeChainArgs a) {
     u32x4 wg0[3][NB], wg1[3][NB];                                    // second Linears of the follow-up MLPs
     if (on0) load_w(a.f[0].w2img6, wg0);
     __syncthreads();
+    SM_TICK(a.stamps, 4);
 
     // ---- stage 2: follow-up MLPs on the new h ---------------------------------------------------------
     {
@@ -658,9 +663,11 @@ node_chain6_kernel(NodeChainArgs a) {
     }
     if (on1) load_w(a.f[1].w2img6, wg1);
     __syncthreads();
+    SM_TICK(a.stamps, 5);
     normalise(pre0, a.f[0].mode, a.f[0].ln_g, a.f[0].ln_b, fhid0);
     if (a.n_follow > 1) normalise(pre1, a.f[1].mode, a.f[1].ln_g, a.f[1].ln_b, fhid1);
     __syncthreads();
+    SM_TICK(a.stamps, 6);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (!(k == 0 ? on0 : on1)) continue;
@@ -683,4 +690,5 @@ node_chain6_kernel(NodeChainArgs a) {
             }
         }
     }
+    SM_STAMP(a.stamps, 7);
 }

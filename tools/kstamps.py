@@ -27,7 +27,7 @@ print(f"waves stamped: {len(st)}; all times in us relative to the earliest stamp
 names = {0: ["start", "weights+tile0 loaded", "all tiles done (stores drained)", "-", "-", "-", "-", "-"],
          1: ["start", "K image in LDS (barrier 1)", "key: rbf + gathered rows summed", "key: GEMM1 (fp32 MFMA)", "key: LayerNorm+ReLU", "key: split", "key: GEMM2+softmax+alpha stores issued", "V image swapped (2 barriers)"]}
 names[2] = names[1]
-names[3] = ["start", "stage1 GEMM1 issued (+W2 loads)", "after barrier 1", "h' computed+stored", "after barrier 2", "follow GEMM1s issued", "after barrier 3", "end"]
+names[3] = ["start", "W1 + [att|h] fragments staged (barrier)", "GEMM1 -> pre (barrier)", "normalise (barrier)", "GEMM2 + h' (barrier)", "follow GEMM1s (barrier)", "normalise x2 (barrier)", "follow GEMM2s + stores drained"]
 nm = names[a.sel if a.sel in names else 1]
 for k in range(8):
     col = st[:, k]; col = col[col > 0]
