@@ -113,8 +113,9 @@ int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, co
  *                        k > 16 always uses the fp32 kernels),
  *          "lin_bf16", "chain_bf16" (1 = node kernels on the bf16 matrix cores with exactly split operands
  *                        [default], 0 = fp32-MFMA node kernels),
- *          "vn_fuse"    (1 = coordinate update fused behind the h2x attention with an in-kernel grid barrier,
- *                        0 = separate vn_stats / vn_apply launches [default: measured equal in graph replay]),
+ *          "vn_fuse"    (2 = VN-linear + batch-norm statistics in the epilogue of the h2x attention, vn_apply as its
+ *                        own launch [default]; 1 = the whole coordinate update behind h2x with an in-kernel grid
+ *                        barrier (no faster: measured); 0 = separate vn_stats / vn_apply launches),
  *          "edge_waves" (waves per workgroup of the edge kernels, 1..12; 0 = automatic: ceil(jobs / CUs) [default]),
  *          "lin_waves"  (1..16 waves per workgroup of node_linear_kernel, tuning),
  *          "stamps", "kstamp_sel" (clock-stamp diagnostics; only meaningful in the --stamps build).

@@ -351,7 +351,7 @@ struct shapemol_ctx {
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 1, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 0;
+    int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 1, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
     int num_cu = 256;
     // profiling
     bool prof_on = false;
@@ -622,16 +622,16 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                                  c->preAB, 8 * H, (has_next && l + 1 < L ? 8 : 4) * NT, n, nullptr)) return 1;
         }
         float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
-        bool vn_done = false;
+        bool vn_done = false, stats_done = false;
         if (phases && c->edge_bf16 == 1) {   // h2x attention, both images resident in LDS
             EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H,
                              (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
-            if (c->vn_fuse) {   // coordinate update behind the attention, in the same launch (grid barrier inside)
+            if (c->vn_fuse) {   // VN-linear + batch statistics (2) or the whole coordinate update (1: grid barrier inside) behind the attention
                 double *tail = c->bn_acc + (size_t)L * kBnReplicas * 2 * hd;
                 fa.vn = {c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o), c->P(Dl.wd_o),
                          c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd,
-                         reinterpret_cast<unsigned *>(tail + l), reinterpret_cast<int *>(tail + L), x_next, 1};
-                vn_done = true;
+                         reinterpret_cast<unsigned *>(tail + l), reinterpret_cast<int *>(tail + L), x_next, c->vn_fuse == 1 ? 1 : 2};
+                if (c->vn_fuse == 1) vn_done = true; else stats_done = true;
             }
             if (launch_fused<H, true>(c, s, fa)) return 1;
         } else if (phases) {   // h2x attention (separate launches)
@@ -648,7 +648,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                   c->P(Dl.wd_o), c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, x_next, n, hd};
         const int per_blk = 256 / hd;
         if (!vn_done) {
-            LAUNCH("vn_stats", hipLaunchKernelGGL(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(kVnThreads), 0, s, va));
+            if (!stats_done) LAUNCH("vn_stats", hipLaunchKernelGGL(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(kVnThreads), 0, s, va));
             LAUNCH("vn_apply", hipLaunchKernelGGL(vn_apply_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
         }
         cur_x = x_next;

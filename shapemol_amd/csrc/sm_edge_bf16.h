@@ -249,7 +249,7 @@ struct EdgeFusedArgs {
         unsigned *arrive;           // grid-barrier counter of this launch, zeroed likewise
         int *err;                   // set to 1 if the grid barrier timed out (workgroups not co-resident)
         float *x_out;               // [N][3]
-        int enable;
+        int enable;                 // 0 off, 1 whole update (grid barrier inside), 2 VN-linear + statistics only
     } vn;
 };
 constexpr int kVnReplicas = 16;
@@ -517,6 +517,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
             atomicAdd(acc + threadIdx.x, s1);
             atomicAdd(acc + HD + threadIdx.x, s2);
         }
+        if (a.vn.enable == 2) return;        // statistics only: vn_apply_kernel follows as its own launch
         // ---- grid barrier: every workgroup is resident (grid <= CUs, one workgroup per CU), so arrival
         //      counting cannot deadlock; a bounded wait turns a violated assumption into an error flag.
         //      Only device-scope atomics cross workgroups here (the sums and the counter): no cache fence is
