@@ -125,7 +125,7 @@ struct DevLayer {
 };
 struct DevModel {
     size_t tab[7];
-    size_t te1w, te1b, te2w, te2b, embw, embb;
+    size_t te1w, te1b, te2w, te2b, embw, embb, embwT;
     DevMlp ew, inv;
     DevMlpImg vhead;             // Linear -> SSP -> Linear (second image padded to 16 rows)
     std::vector<DevLayer> layer;
@@ -427,6 +427,7 @@ int set_edge_attr(int KP) {
 #define SETATTR3(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4 + 12 * 512));
+    HIPCHK(hipFuncSetAttribute((const void *)node_prologue6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * Chain6Lds<H>::FRAG * 16 + Chain6Lds<H>::PRE * 4)));
     HIPCHK(hipFuncSetAttribute((const void *)node_chain6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain6Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin6Chunk * 3 * H * 32));
     if (KP == 8) { SETATTR1(8) SETATTR2(8) SETATTR3(8) } else if (KP == 16) { SETATTR1(16) SETATTR2(16) SETATTR3(16) } else { SETATTR(32) }
@@ -562,7 +563,23 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     const int n = (int)N;
     AtomEmbArgs ae{c->P(c->dm.embw), c->P(c->dm.embb), v_in, c->mol_of, c->ttab, c->t_mol, sampling ? c->steps : nullptr,
                    c->steps + 1, c->bn_acc, c->h_a, n, H, C, D, t_first, L * kBnReplicas * 2 * hd + L};   // + the grid-barrier counters
-    LAUNCH("embed", hipLaunchKernelGGL(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
+    const int nlay = c->stop_layer >= 0 ? std::min(c->stop_layer, L) : L;
+    const bool fused_prologue = c->chain_bf16 && c->lin_bf16;   // embedding + first queries + first per-node products in one launch
+    if (fused_prologue) {
+        const DevLayer &D0 = c->dm.layer[0];
+        NodePrologueArgs pa{};
+        pa.emb_wT = c->P(c->dm.embwT); pa.emb_b = ae.b; pa.v = v_in; pa.mol_of = c->mol_of; pa.ttab = c->ttab; pa.t_mol = c->t_mol;
+        pa.step_ptr = ae.step_ptr; pa.step_cur = ae.step_cur; pa.bn_acc = c->bn_acc; pa.h_out = c->h_a;
+        pa.q = follow_of(c, D0.q_x2h, NODE_LN_RELU, c->q_x, H, H);
+        pa.lin_img6 = c->P(D0.pre6_x2h); pa.add_mol = c->add0; pa.pre_out = c->pre0;
+        pa.n_lin_tiles = nlay > 0 ? 4 * (H / 16) : 0; pa.ld_add = 4 * H; pa.ld_out = 4 * H;
+        pa.n_atoms = n; pa.C = C; pa.D = D; pa.t_first = t_first; pa.bn_acc_len = ae.bn_acc_len;
+        const int n_ct = (n + 15) / 16;
+        LAUNCH("node_prologue", hipLaunchKernelGGL(node_prologue6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
+                                                   2 * Chain6Lds<H>::FRAG * 16 + Chain6Lds<H>::PRE * 4, s, pa));
+    } else {
+        LAUNCH("embed", hipLaunchKernelGGL(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
+    }
     LAUNCH("knn", hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x_in, c->mol_of, c->mol_off, n, g.knn, KP, c->nbr));
     EdgeWeightArgs ea{x_in, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
                       c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, n * KP, KP};
@@ -572,10 +589,9 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     }
     const float *cur_x = x_in;
     float *cur_h = c->h_a;
-    const int nlay = c->stop_layer >= 0 ? std::min(c->stop_layer, L) : L;
     constexpr int NT = H / 16;
     bool v_done = false;
-    if (nlay > 0) {   // prologue: per-node products and queries of the first x2h attention
+    if (nlay > 0 && !fused_prologue) {   // prologue: per-node products and queries of the first x2h attention
         const DevLayer &D0 = c->dm.layer[0];
         if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(D0.pre_x2h), c->P(D0.pre6_x2h), c->add0, 4 * H, c->pre0, 4 * H, 4 * NT, n,
                              c->kstamp_sel == 0 ? c->kstamps : nullptr)) return 1;
@@ -730,6 +746,9 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
     dm.te1w = im.put(hm.te1.w, (size_t)hm.te1.out * hm.te1.in); dm.te1b = im.put(hm.te1.b, hm.te1.out);
     dm.te2w = im.put(hm.te2.w, (size_t)hm.te2.out * hm.te2.in); dm.te2b = im.put(hm.te2.b, hm.te2.out);
     dm.embw = im.put(hm.emb.w, (size_t)hm.emb.out * hm.emb.in); dm.embb = im.put(hm.emb.b, hm.emb.out);
+    dm.embwT = im.alloc((size_t)hm.emb.in * hm.emb.out);          // [C + D][H]
+    for (int f = 0; f < hm.emb.out; ++f)
+        for (int k = 0; k < hm.emb.in; ++k) im.d[dm.embwT + (size_t)k * hm.emb.out + f] = hm.emb.w[(size_t)f * hm.emb.in + k];
     auto put_mlp = [&](const Mlp &m) {
         DevMlp d;
         d.w1 = im.put(m.l1.w, (size_t)m.l1.out * m.l1.in); d.b1 = im.put(m.l1.b, m.l1.out);

@@ -692,3 +692,198 @@ node_chain6_kernel(NodeChainArgs a) {
     }
     SM_STAMP(a.stamps, 7);
 }
+
+// -------------------------------------------------------------------------------------------------
+// node_prologue6_kernel: everything on the node side that precedes the first attention of an evaluation, in
+// one launch (it replaces atom_embed_kernel + node_mlp2_kernel + node_linear6_kernel at layer 0):
+//     h0 = ligand_atom_emb([one_hot(v) | time_emb])          (molopt_score_model.py:292-301), stored and split
+//     q  = query MLP of the first x2h attention on h0         (uni_transformer.py:68)
+//     pre0 = per-node halves of that attention's edge MLPs:   h0 W^T + per-molecule term  ([N][4H])
+// plus the per-evaluation bookkeeping (latch the step counter, clear the batch-norm accumulators).
+// Same team layout and bf16x6 arithmetic as node_chain6_kernel.
+// -------------------------------------------------------------------------------------------------
+struct NodePrologueArgs {
+    const float *emb_wT, *emb_b;  // [C + D][H] (transposed: a lane's four features are one 16-byte load), [H]
+    const int64_t *v;             // [N]
+    const int *mol_of;
+    const float *ttab;            // [T][D]
+    const int *t_mol;             // [B] timestep per molecule (score API)
+    const int *step_ptr;          // sampling: device step counter (t = t_first - step), else nullptr
+    int *step_cur;
+    double *bn_acc;               // zeroed here
+    float *h_out;                 // [N][H]
+    NodeFollow q;                 // query MLP -> q.out
+    const float *lin_img6;        // split image of [n_lin_tiles * 16][H]
+    const float *add_mol;         // [B][ld_add] per-molecule term of the linear outputs
+    float *pre_out;               // [N][ld_out]
+    int n_lin_tiles, ld_add, ld_out;
+    int n_atoms, C, D, t_first, bn_acc_len;
+};
+
+template <int H>
+__global__ void __launch_bounds__(H * 4)
+node_prologue6_kernel(NodePrologueArgs a) {
+    using L = Chain6Lds<H>;
+    constexpr int NT = H / 16, NB = H / 32, CC = CHAIN_COLS, XS = L::XS;
+    constexpr int LPC = NB * 4;
+    static_assert(CC == 2, "the normalise pass covers exactly 32 columns");
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain6_lds[];
+    u32x4 *fh = reinterpret_cast<u32x4 *>(chain6_lds);      // fragments of h0
+    u32x4 *fhid = fh + L::FRAG;                             // hidden tile of the query MLP
+    float *pre0 = reinterpret_cast<float *>(fh + 2 * L::FRAG);
+    const int lane = threadIdx.x & 63, ot = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int ct0 = blockIdx.x * CC;
+    const int f0 = 16 * ot + 4 * g;
+
+    auto load_w = [&](const float *img, int tile, u32x4 (&w)[3][NB]) {
+        const u32x4 *wi = reinterpret_cast<const u32x4 *>(img) + (size_t)tile * 3 * NB * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) w[p][b] = wi[(p * NB + b) * 64];
+    };
+    auto gemm6 = [&](const u32x4 (&w)[3][NB], const u32x4 *f, f32x4 (&acc)[CC]) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            u32x4 xh[CC], xm[CC], xl[CC];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                xh[c] = f[((0 * NB + b) * CC + c) * 64 + lane];
+                xm[c] = f[((1 * NB + b) * CC + c) * 64 + lane];
+                xl[c] = f[((2 * NB + b) * CC + c) * 64 + lane];
+            }
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[2][b], xh[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[1][b], xm[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[0][b], xl[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[1][b], xh[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[0][b], xm[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[0][b], xh[c], acc[c]);
+        }
+    };
+    auto atom_of = [&](int c) { return min((ct0 + c) * 16 + n, a.n_atoms - 1); };
+    auto atom_ok = [&](int c) { return (ct0 + c) * 16 + n < a.n_atoms; };
+
+    // ---- bookkeeping of the evaluation ------------------------------------------------------------------
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    {
+        const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+        if (gid == 0 && a.step_ptr) *a.step_cur = step;
+        for (int i = gid; i < a.bn_acc_len; i += gridDim.x * blockDim.x) a.bn_acc[i] = 0.0;
+    }
+    // ---- stage 0: embedding of the workgroup's atoms -> global h0 and LDS fragments ----------------------
+    u32x4 wq1[3][NB], wl[3][NB];
+    load_w(a.q.w1img6, ot, wq1);
+    for (int idx = threadIdx.x; idx < CC * NB * 64; idx += NT * 64) {
+        const int sl = idx & 63, sb = (idx >> 6) % NB, sc = idx / (64 * NB);
+        const int at_raw = (ct0 + sc) * 16 + (sl & 15);
+        const int at = min(at_raw, a.n_atoms - 1);
+        const int t = a.step_ptr ? a.t_first - step : a.t_mol[a.mol_of[at]];
+        const float *te = a.ttab + (size_t)t * a.D;
+        const int vi = (int)a.v[at];
+        const int fa = 32 * sb + 4 * (sl >> 4);
+        float vv[8];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                      // y = (b + W[:, v]) + sum_k W[:, C + k] te[k], k ascending
+            const int f = fa + 16 * hf;
+            const float4 bb = ldg4(a.emb_b + f), wv = ldg4(a.emb_wT + (size_t)vi * H + f);
+            float y[4] = {bb.x + wv.x, bb.y + wv.y, bb.z + wv.z, bb.w + wv.w};
+            for (int k = 0; k < a.D; ++k) {
+                const float4 wk = ldg4(a.emb_wT + (size_t)(a.C + k) * H + f);
+                const float tk = te[k];
+                y[0] += wk.x * tk; y[1] += wk.y * tk; y[2] += wk.z * tk; y[3] += wk.w * tk;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vv[4 * hf + j] = y[j];
+        }
+        if (at_raw < a.n_atoms) {
+            stg4(a.h_out + (size_t)at * H + fa, float4{vv[0], vv[1], vv[2], vv[3]});
+            stg4(a.h_out + (size_t)at * H + fa + 16, float4{vv[4], vv[5], vv[6], vv[7]});
+        }
+        u32x4 hi, mid, lo;
+        split3_bf16(vv, hi, mid, lo);
+        u32x4 *dst = fh + (sb * CC + sc) * 64 + sl;
+        dst[0] = hi; dst[NB * CC * 64] = mid; dst[2 * NB * CC * 64] = lo;
+    }
+    if (a.n_lin_tiles > 0) load_w(a.lin_img6, ot, wl);
+    const float4 b1 = ldg4(a.q.b1 + f0);
+    __syncthreads();
+
+    // ---- stage 1: first Linear of the query MLP; the per-node linear outputs of the edge MLPs ------------
+    {
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{b1.x, b1.y, b1.z, b1.w};
+        gemm6(wq1, fh, acc);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) stg4(pre0 + (c * 16 + n) * XS + f0, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
+    }
+    const bool onq = ot < a.q.nt2;
+    if (onq) load_w(a.q.w2img6, ot, wq1);                    // second Linear of the query MLP (reuses the registers)
+    // linear outputs: tiles ot, ot + NT, ... (4 per wave for the [N][4H] products); weights alternate between two
+    // register sets so that the next block is in flight during the current product
+    auto lin_tile = [&](int tile, const u32x4 (&w)[3][NB]) {
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const float4 t = a.add_mol ? ldg4(a.add_mol + (size_t)a.mol_of[atom_of(c)] * a.ld_add + 16 * tile + 4 * g)
+                                       : float4{0.f, 0.f, 0.f, 0.f};
+            acc[c] = f32x4{t.x, t.y, t.z, t.w};
+        }
+        gemm6(w, fh, acc);
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            if (atom_ok(c)) stg4(a.pre_out + (size_t)atom_of(c) * a.ld_out + 16 * tile + 4 * g, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
+    };
+    for (int tile = ot; tile < a.n_lin_tiles; tile += 2 * NT) {
+        u32x4 wn[3][NB];
+        const bool more1 = tile + NT < a.n_lin_tiles, more2 = tile + 2 * NT < a.n_lin_tiles;
+        if (more1) load_w(a.lin_img6, tile + NT, wn);
+        lin_tile(tile, wl);
+        if (more2) load_w(a.lin_img6, tile + 2 * NT, wl);
+        if (more1) lin_tile(tile + NT, wn);
+    }
+    __syncthreads();
+    {   // LayerNorm + ReLU of the hidden tile -> fragments (LPC lanes per column, as in node_chain6_kernel)
+        const int col = ot * (64 / LPC) + lane / LPC, ln = lane % LPC;
+        const int b = ln >> 2, gg = ln & 3;
+        const int fa = 32 * b + 4 * gg;
+        const float4 p0 = ldg4(pre0 + col * XS + fa), p1 = ldg4(pre0 + col * XS + fa + 16);
+        float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+        const float mean = seg_sum<LPC>(s) * (1.0f / H);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; q += d * d; }
+        const float var = seg_sum<LPC>(q) * (1.0f / H);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float4 g0 = ldg4(a.q.ln_g + fa), g1 = ldg4(a.q.ln_g + fa + 16), e0 = ldg4(a.q.ln_b + fa), e1 = ldg4(a.q.ln_b + fa + 16);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf((v[i] - mean) * rstd * ga[i] + be[i], 0.f);
+        u32x4 hi, mid, lo;
+        split3_bf16(v, hi, mid, lo);
+        u32x4 *dst = fhid + (b * CC + (col >> 4)) * 64 + gg * 16 + (col & 15);
+        dst[0] = hi; dst[NB * CC * 64] = mid; dst[2 * NB * CC * 64] = lo;
+    }
+    __syncthreads();
+    if (onq) {
+        const float4 b = ldg4(a.q.b2 + f0);
+        f32x4 acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = f32x4{b.x, b.y, b.z, b.w};
+        gemm6(wq1, fhid, acc);
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            if (atom_ok(c)) stg4(a.q.out + (size_t)atom_of(c) * a.q.ld_out + f0, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
+    }
+}
