@@ -24,5 +24,8 @@ for st in steps:
     acc = collections.Counter()
     for s, e, n in st: acc[n] += e - s
     for n, v in acc.items(): per[n].append(v)
+# kernels that run in every analysed step (per-chain preparation kernels and copies appear in a few steps only)
 for n, v in sorted(per.items(), key=lambda kv: -S.median(kv[1])):
+    if len(v) * 2 < len(steps):
+        continue
     print(f"  {n[-46:]:46s} {S.median(v)/1e3:8.1f} us/step")
