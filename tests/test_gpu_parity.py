@@ -123,6 +123,16 @@ def test_forward_b256_vs_oracle():
         out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
     for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
         assert maxabs(out[k], ref[k]) < FWD_TOL, k
+    # the same evaluation with ONE wave per workgroup of the edge kernels: ~11 jobs per wave instead of one, i.e. the
+    # multi-job paths (next job's loads in flight, per-job statistics of the fused epilogue) that larger batches take
+    try:
+        m.set_option("edge_waves", 1)
+        with torch.no_grad():
+            out2 = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
+    finally:
+        m.set_option("edge_waves", 0)
+    for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+        assert maxabs(out2[k], ref[k]) < FWD_TOL, k
 
 
 def _chain(m, init_pos, init_v, batch, shape, steps, eps, u, **kw):
