@@ -1,18 +1,21 @@
-// Edge attention as per-MLP PHASE kernels with the second Linear on the bf16 matrix cores.
+// Edge attention with the second Linear of the edge MLPs on the bf16 matrix cores (the default kernels).
 //
 // Same semantics and formulation as sm_edge.h (reference: models/uni_transformer.py:48-81 for x2h,
 // :121-151 for h2x).  Differences:
 //   * the H x H (or heads x H) second Linear of each edge MLP is evaluated as six bf16 MFMA products of
-//     exactly split operands (sm_device.h, gemm_bf16x6): fp32-level accuracy at ~2.7x the fp32-MFMA
-//     rate, on the matrix pipe, so the LayerNorm / softmax / reduction VALU work overlaps with it;
-//   * the split weights take 6 bytes per element, so only ONE MLP fits in LDS: the key path and the
-//     value path are separate phases (launches) that hand the attention weights over through a small
-//     global buffer  alpha[N * KP][2][NT]  (16 floats per edge slot at H = 128):
-//         PH_K  : logits + per-atom softmax over the neighbour slots           -> alpha
-//         PH_VX : x2h values, sum_j alpha * e_w * v_ij                          -> att [N][H]
-//         PH_VH : h2x values (one per head), sum_j alpha * e_w * v_ij * rel_x   -> o3  [N][16][3]
-// One job = the KP <= 16 neighbour slots of 16 / KP centre atoms = one 16-column tile, as in
-// edge_attention_t1_kernel; loads of a job are issued before the weight image is copied to LDS.
+//     exactly split operands (sm_device.h, gemm_bf16x6 / tile_bf16x6): fp32-level accuracy at ~2.7x the
+//     fp32-MFMA rate, on the matrix pipe, where vector work can issue beside it;
+//   * the split weights take 6 bytes per element, so only ONE full-width MLP fits in LDS: the key path and
+//     the value path are separate PHASES that hand the attention weights over through a small global
+//     buffer  alpha[N * KP][2][NT]  (16 floats per edge slot at H = 128):
+//         key    : logits + per-atom softmax over the neighbour slots           -> alpha
+//         value x: x2h values, sum_j alpha * e_w * v_ij                          -> att [N][H]
+//         value h: h2x values (one per head), sum_j alpha * e_w * v_ij * rel_x   -> o3  [N][16][3]
+//   * edge_fused_kernel (default) runs both phases of an attention in one launch (image swap in LDS for x2h,
+//     both images resident for h2x) and, for h2x, the VN-linear + batch-norm statistics of the coordinate
+//     update in its epilogue; edge_phase_kernel runs one phase per launch (option edge_bf16 = 2).
+// One job = the KP <= 16 neighbour slots of 16 / KP centre atoms = one 16-column tile, one job per wave where
+// the jobs fit; loads of a job are issued before the weight image is copied to LDS.
 #pragma once
 #include "sm_device.h"
 #ifndef SM_ABLATE

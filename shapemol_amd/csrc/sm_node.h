@@ -1,4 +1,7 @@
-// Node kernels: every per-atom Linear / MLP of the score network on fp32 MFMA.
+// Node kernels: every per-atom Linear / MLP of the score network.  The default path is the bf16x6 family in
+// the second half of this file (node_linear6_kernel, node_chain6_kernel, node_prologue6_kernel: exactly split
+// operands on the bf16 matrix cores, activations kept in LDS as ready-made fragments); the fp32-MFMA kernels
+// described next are the first version, kept behind shapemol_set_option("lin_bf16" / "chain_bf16", 0).
 //
 // Reference semantics (paths relative to the reference repository):
 //   MLP = Linear -> LayerNorm -> ReLU -> Linear          models/common.py:47-67
