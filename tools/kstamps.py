@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from shapemol_amd import ScorePosNet3D, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--sel", type=int, default=1); ap.add_argument("--batch", type=int, default=256)
-ap.add_argument("--waves", type=int, default=0)
+ap.add_argument("--waves", type=int, default=0); ap.add_argument("--chain", type=int, default=0)
 a = ap.parse_args()
 cfg = yaml.safe_load(open(os.path.join(ROOT, "config/training/dgcnn_signeddist_512_attention_residue_uniform_pos0_10_pos1.e-7_0.01_6_v001.yml")))["model"]
 m = ScorePosNet3D(cfg, 15); m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(cfg, 7).items()}); m = m.to("cuda:0")
@@ -19,7 +19,13 @@ m(*args); m.set_option("edge_waves", a.waves)
 for _ in range(3): m(*args)
 torch.cuda.synchronize()
 m.set_option("kstamp_sel", a.sel)
-m(*args); torch.cuda.synchronize()
+if a.chain > 0:      # stamp the selected launch of the LAST step of a running chain (clocks and caches as in production)
+    from shapemol_amd.runtime import ChainRunner
+    r = ChainRunner(m, len(bb["batch"]), a.batch, a.chain, keep_traj=False)
+    r.load_batch(bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"])
+    r.run(a.chain); r.synchronize()
+else:
+    m(*args); torch.cuda.synchronize()
 st = m.debug_read("kstamps", (4096 * 16, 8), np.uint64).astype(np.int64)
 st = st[st[:, 0] > 0]
 t0 = st[:, 0].min()
