@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=6, help="reverse steps of the CPU oracle to time (0 = skip)")
     ap.add_argument("--no-traj", action="store_true", help="do not keep per-step trajectories")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--concurrent", type=int, default=2,
+                    help="also report the throughput of this many independent batch-256 chains run concurrently on the GPU "
+                         "(extra field, never `value`; 0/1 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,6 +203,33 @@ def main():
             "breakdown_ms_per_step": {k: round(v[0] / max(1, args.profile_steps), 4) for k, v in prof.items()},
         }
         log("profile pass done: " + ", ".join(f"{k}={v[0] / max(1, args.profile_steps):.3f}ms" for k, v in prof.items()))
+        # ---- throughput mode: independent chains side by side (extra field; `value` stays the single-chain number) ----
+        if world == 1 and args.concurrent > 1 and use_graph:
+            runners = [runner]
+            for j in range(1, args.concurrent):
+                mj = ScorePosNet3D(cfg, 15)
+                mj.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+                mj = mj.to(dev)
+                bj = synth.synthetic_batch(args.batch, seed=3021 + j)
+                rj = ChainRunner(mj, len(bj["batch"]), args.batch, max(steps, warm, 1), keep_traj=not args.no_traj, device=dev)
+                rj.load_batch(bj["init_pos"], bj["init_v"], bj["batch"], bj["shape"])
+                runners.append(rj)
+            for r_ in runners:
+                r_.run(max(warm, 5), seed=21, use_graph=True)
+            for r_ in runners:
+                r_.synchronize()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for r_ in runners:
+                r_.run(steps, seed=22, use_graph=True)
+            for r_ in runners:
+                r_.synchronize()
+            dtc = time.perf_counter() - t1
+            out["concurrent_chains"] = {"chains": len(runners), "value": round(len(runners) * args.batch / (CHAIN_STEPS * dtc / steps), 3),
+                                        "unit": "molecules/s", "ms_per_step_all_chains": round(dtc / steps * 1e3, 4),
+                                        "note": "independent batch-256 chains (own batch-norm statistics each) on separate streams of one GPU"}
+            log(f"concurrent chains: {out['concurrent_chains']}")
+            del runners
         # trajectory D2H cost (reported, never part of value)
         if not args.no_traj:
             torch.cuda.synchronize()
