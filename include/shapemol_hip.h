@@ -36,7 +36,7 @@ extern "C" {
 
 typedef struct shapemol_ctx shapemol_ctx;
 
-/* `model` section of the training YAML (config/training/*.yml:21-74), reduced to what the path uses. */
+/* `model` section of the training YAML (the YAML files under config/training, lines 21-74), reduced to what the path uses. */
 typedef struct shapemol_config {
     int32_t hidden_dim;        /* 128 */
     int32_t n_heads;           /* 16  (hidden_dim / n_heads must be 8) */

@@ -88,6 +88,17 @@ def test_library_exports_every_header_symbol():
     assert lib.shapemol_abi_version() == 1
 
 
+def test_header_is_plain_c():
+    """The boundary header is a C header (no C++ / HIP / torch types): it must compile as C99 with -Wall -Werror."""
+    import shutil, subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "shapemol_hip.h")
+    r = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_pack_matches_library_weight_count():
     from shapemol_amd import _lib, pack_state_dict
     lib = _lib.load()
