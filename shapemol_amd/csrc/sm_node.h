@@ -484,11 +484,18 @@ node_chain_kernel(NodeChainArgs a) {
 //     column, two-pass statistics over a DPP row segment) -- one more barrier per MLP, ~8x less vector work;
 //   * weight blocks are resident per wave as 3 x K/32 fragments of 4 VGPRs, requested a stage ahead.
 // -------------------------------------------------------------------------------------------------
+// Slot of lane `l` inside the 64-slot block of k-step `b` of a fragment buffer.  Consumers read a block with all 64
+// lanes (any bijection is conflict-free for them); the normalise pass WRITES it with the 16 lanes of a column, which hold
+// the same n and different (k-step, lane group): un-swizzled those stores hit one bank group (8-way conflicts, 45 % of
+// the kernel's LDS cycles per SQ_LDS_BANK_CONFLICT).  XOR-ing n with (group, k-step parity) spreads them over the banks.
+SM_DEV int frag_slot(int b, int l) { return (l & 48) | ((l ^ (((l >> 4) << 1) | (b & 1))) & 15); }
+
 template <int H>
 struct Chain6Lds {
     static constexpr int NB = H / 32, CC = CHAIN_COLS;
     static constexpr int FRAG = 3 * NB * CC * 64;          // u32x4 per fragment buffer of K = H
-    static constexpr int XS = H + 16;                      // fp32 pre-activation row stride
+    static constexpr int XS = H + 4;                       // fp32 pre-activation row stride: rows 16 B apart modulo 128 B,
+                                                           // so the eight rows of a store group use different banks
     static constexpr int PRE = CC * 16 * XS;               // floats per pre-activation buffer
     static constexpr size_t BYTES = (size_t)3 * FRAG * 16 + (size_t)2 * PRE * 4;
 };
@@ -526,9 +533,9 @@ node_chain6_kernel(NodeChainArgs a) {
             u32x4 xh[CC], xm[CC], xl[CC];
 #pragma unroll
             for (int c = 0; c < CC; ++c) {
-                xh[c] = f[((0 * KB + b) * CC + c) * 64 + lane];
-                xm[c] = f[((1 * KB + b) * CC + c) * 64 + lane];
-                xl[c] = f[((2 * KB + b) * CC + c) * 64 + lane];
+                xh[c] = f[((0 * KB + b) * CC + c) * 64 + frag_slot(b, lane)];
+                xm[c] = f[((1 * KB + b) * CC + c) * 64 + frag_slot(b, lane)];
+                xl[c] = f[((2 * KB + b) * CC + c) * 64 + frag_slot(b, lane)];
             }
 #pragma unroll
             for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[2][b], xh[c], acc[c]);      // smallest terms first
@@ -576,7 +583,7 @@ node_chain6_kernel(NodeChainArgs a) {
         }
         u32x4 hi, mid, lo;
         split3_bf16(v, hi, mid, lo);
-        u32x4 *dst = fo + (b * CC + (col >> 4)) * 64 + gg * 16 + (col & 15);
+        u32x4 *dst = fo + (b * CC + (col >> 4)) * 64 + frag_slot(b, gg * 16 + (col & 15));
         dst[0] = hi; dst[NB * CC * 64] = mid; dst[2 * NB * CC * 64] = lo;
     };
     auto atom_of = [&](int c) { return min((ct0 + c) * 16 + n, a.n_atoms - 1); };
@@ -594,7 +601,7 @@ node_chain6_kernel(NodeChainArgs a) {
         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         u32x4 hi, mid, lo;
         split3_bf16(v, hi, mid, lo);
-        u32x4 *dst = fin + (sb * CC + sc) * 64 + sl;
+        u32x4 *dst = fin + (sb * CC + sc) * 64 + frag_slot(sb, sl);
         dst[0] = hi; dst[2 * NB * CC * 64] = mid; dst[2 * 2 * NB * CC * 64] = lo;
     }
     load_w(a.w2img6, w2);
@@ -634,7 +641,7 @@ node_chain6_kernel(NodeChainArgs a) {
             unsigned ph[2], pm[2], pl[2];
             split3_pair(hn.x, hn.y, ph[0], pm[0], pl[0]);
             split3_pair(hn.z, hn.w, ph[1], pm[1], pl[1]);
-            uint2 *dst = reinterpret_cast<uint2 *>(fh + ((ot >> 1) * CC + c) * 64 + lane) + (ot & 1);
+            uint2 *dst = reinterpret_cast<uint2 *>(fh + ((ot >> 1) * CC + c) * 64 + frag_slot(ot >> 1, lane)) + (ot & 1);
             dst[0] = uint2{ph[0], ph[1]};
             dst[NB * CC * 64 * 2] = uint2{pm[0], pm[1]};
             dst[2 * NB * CC * 64 * 2] = uint2{pl[0], pl[1]};
@@ -752,9 +759,9 @@ node_prologue6_kernel(NodePrologueArgs a) {
             u32x4 xh[CC], xm[CC], xl[CC];
 #pragma unroll
             for (int c = 0; c < CC; ++c) {
-                xh[c] = f[((0 * NB + b) * CC + c) * 64 + lane];
-                xm[c] = f[((1 * NB + b) * CC + c) * 64 + lane];
-                xl[c] = f[((2 * NB + b) * CC + c) * 64 + lane];
+                xh[c] = f[((0 * NB + b) * CC + c) * 64 + frag_slot(b, lane)];
+                xm[c] = f[((1 * NB + b) * CC + c) * 64 + frag_slot(b, lane)];
+                xl[c] = f[((2 * NB + b) * CC + c) * 64 + frag_slot(b, lane)];
             }
 #pragma unroll
             for (int c = 0; c < CC; ++c) acc[c] = mfma_bf16(w[2][b], xh[c], acc[c]);
@@ -811,7 +818,7 @@ node_prologue6_kernel(NodePrologueArgs a) {
         }
         u32x4 hi, mid, lo;
         split3_bf16(vv, hi, mid, lo);
-        u32x4 *dst = fh + (sb * CC + sc) * 64 + sl;
+        u32x4 *dst = fh + (sb * CC + sc) * 64 + frag_slot(sb, sl);
         dst[0] = hi; dst[NB * CC * 64] = mid; dst[2 * NB * CC * 64] = lo;
     }
     if (a.n_lin_tiles > 0) load_w(a.lin_img6, ot, wl);
@@ -875,7 +882,7 @@ node_prologue6_kernel(NodePrologueArgs a) {
         for (int i = 0; i < 8; ++i) v[i] = fmaxf((v[i] - mean) * rstd * ga[i] + be[i], 0.f);
         u32x4 hi, mid, lo;
         split3_bf16(v, hi, mid, lo);
-        u32x4 *dst = fhid + (b * CC + (col >> 4)) * 64 + gg * 16 + (col & 15);
+        u32x4 *dst = fhid + (b * CC + (col >> 4)) * 64 + frag_slot(b, gg * 16 + (col & 15));
         dst[0] = hi; dst[NB * CC * 64] = mid; dst[2 * NB * CC * 64] = lo;
     }
     __syncthreads();
