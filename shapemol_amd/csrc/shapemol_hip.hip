@@ -31,6 +31,10 @@ int fail(const std::string &m) { g_err = m; return 1; }
     } while (0)
 
 constexpr int kEdgeThreadsDefault = 768;
+#ifndef SM_GRAPH_UNROLL
+#define SM_GRAPH_UNROLL 8
+#endif
+constexpr int kGraphUnroll = SM_GRAPH_UNROLL;   // reverse steps per graph launch
 
 // ---- host view of the packed weight array (order documented in shapemol_amd/packing.py) ----
 struct Lin { const float *w = nullptr, *b = nullptr; int out = 0, in = 0; };
@@ -357,7 +361,7 @@ struct shapemol_ctx {
     bool prof_on = false;
     std::vector<ProfRec> prof;
     // graph cache
-    hipGraphExec_t gexec = nullptr;
+    hipGraphExec_t gexec = nullptr, gexec_u = nullptr;     // one step / kGraphUnroll steps
     struct GraphKey { int64_t N, B; const void *eps, *u, *tp[6]; uint64_t seed; int steps; bool operator==(const GraphKey &o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; } } gkey{};
     const float *P(size_t off) const { return d_img + off; }
 };
@@ -388,6 +392,7 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
     for (void *p : c->allocs) hipFree(p);
     c->allocs.clear();
     if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->gexec_u) { hipGraphExecDestroy(c->gexec_u); c->gexec_u = nullptr; }
     const int64_t capN = std::max<int64_t>(N, c->capN), capB = std::max<int64_t>(B, c->capB);
     const shapemol_config &g = c->cfg;
     const int H = g.hidden_dim, L = g.num_layers, hd = g.n_heads;
@@ -797,6 +802,7 @@ void shapemol_destroy(shapemol_ctx *c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     if (c->gexec) hipGraphExecDestroy(c->gexec);
+    if (c->gexec_u) hipGraphExecDestroy(c->gexec_u);
     for (auto &r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (void *p : c->allocs) hipFree(p);
     hipFree(c->ttab);
@@ -849,20 +855,31 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
         shapemol_ctx::GraphKey key{};
         key.N = N; key.B = B; key.eps = d_eps; key.u = d_u; key.seed = seed; key.steps = 0;
         if (traj) { key.tp[0] = traj->pos_traj; key.tp[1] = traj->v_traj; key.tp[2] = traj->v0_traj; key.tp[3] = traj->vt_traj; key.tp[4] = traj->pos_cond_traj; key.tp[5] = traj->v_cond_traj; }
-        if (!c->gexec || !(key == c->gkey)) {
-            if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        // two executables: one reverse step, and kGraphUnroll steps back to back (the gap between two graph launches,
+        // ~5 us, is then paid once per kGraphUnroll steps); every step reads its index from the device-side counter
+        auto capture = [&](int n_steps, hipGraphExec_t *exec) -> int {
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int rc = one_step();
+            int rc = 0;
+            for (int i = 0; i < n_steps && !rc; ++i) rc = one_step();
             const hipError_t ce = hipStreamEndCapture(s, &graph);
             if (rc) { if (graph) hipGraphDestroy(graph); return 1; }
             if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-            const hipError_t ie = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+            const hipError_t ie = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
             hipGraphDestroy(graph);
-            if (ie != hipSuccess) { c->gexec = nullptr; return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+            if (ie != hipSuccess) { *exec = nullptr; return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+            return 0;
+        };
+        if (!c->gexec || !(key == c->gkey)) {
+            if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+            if (c->gexec_u) { hipGraphExecDestroy(c->gexec_u); c->gexec_u = nullptr; }
+            if (capture(1, &c->gexec)) return 1;
             c->gkey = key;
         }
-        for (int st = 0; st < num_steps; ++st) HIPCHK(hipGraphLaunch(c->gexec, s));
+        if (num_steps >= kGraphUnroll && !c->gexec_u && capture(kGraphUnroll, &c->gexec_u)) return 1;
+        int st = 0;
+        for (; st + kGraphUnroll <= num_steps; st += kGraphUnroll) HIPCHK(hipGraphLaunch(c->gexec_u, s));
+        for (; st < num_steps; ++st) HIPCHK(hipGraphLaunch(c->gexec, s));
     } else {
         for (int st = 0; st < num_steps; ++st) if (one_step()) return 1;
     }
@@ -895,6 +912,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     else if (k == "edge_waves") { if (value < 0 || value > 12) return fail("edge_waves must be 0 (automatic) .. 12"); c->edge_threads = (int)value * 64; }   // 0 = automatic
     else return fail("unknown option " + k);
     if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->gexec_u) { hipGraphExecDestroy(c->gexec_u); c->gexec_u = nullptr; }
     return 0;
 }
 
