@@ -112,6 +112,36 @@ def test_forward_variants_golden(tag):
         assert maxabs(out[k], f[k]) < FWD_TOL, k
 
 
+@pytest.mark.parametrize("k", [4, 12, 16])
+def test_forward_other_k_vs_oracle(k):
+    """Neighbour counts other than the configured 8: k = 4 (half-empty 8-slot tiles), k = 12 and 16 (the 16-slot,
+    one-atom-per-job instantiation of the edge kernels), with molecules both smaller and larger than k + 1."""
+    m = hip_model(seed=5, knn=k)
+    sd, dm, _, _ = oracle_model(seed=5, knn=k)
+    bb = synth.synthetic_batch(12, seed=77, atoms_range=(6, 30))
+    t = (synth.hash_u24(12, 3, 3) % 1000).astype(np.int64)
+    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    with torch.no_grad():
+        out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
+    for key in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+        assert maxabs(out[key], ref[key]) < FWD_TOL, key
+
+
+@pytest.mark.parametrize("nmol,rng", [(1, (17, 17)), (1, (1, 1)), (3, (33, 48))], ids=["one_molecule", "one_atom", "large_molecules"])
+def test_forward_extreme_batches_vs_oracle(nmol, rng):
+    """A batch of a single molecule, of a single atom (no edges at all; batch-norm over one sample), and molecules larger
+    than anything in the MOSES prior."""
+    m = hip_model()
+    sd, dm, _, _ = oracle_model()
+    bb = synth.synthetic_batch(nmol, seed=31, atoms_range=rng)
+    t = np.full(nmol, 321, np.int64)
+    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    with torch.no_grad():
+        out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
+    for key in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+        assert maxabs(out[key], ref[key]) < FWD_TOL, key
+
+
 def test_forward_b256_vs_oracle():
     """BASELINE config-2 size (256 molecules, ~5.5k atoms) against the CPU oracle, one evaluation."""
     m = hip_model()
