@@ -67,6 +67,7 @@ def _check_device_tensor(name, t, dtype):
 
 
 class ScorePosNet3D(nn.Module):
+    _accelerated = True      # shapemol_amd.sampling: this sample_diffusion takes the private host-buffer keyword
 
     def __init__(self, config, ligand_atom_feature_dim):
         super().__init__()
@@ -189,7 +190,8 @@ class ScorePosNet3D(nn.Module):
     def sample_diffusion(self, init_ligand_pos, init_ligand_v, batch_ligand, ligand_shape, threshold_type=None,
                          threshold_args=None, num_steps=None, center_pos_mode=None, use_grad=False, grad_lr=1,
                          shape_AE=None, use_mesh_data=None, use_pointcloud_data=None, grad_step=500,
-                         guide_stren=0, bounds=None, *, noise=None, seed=None, return_traj=True, use_graph=True):
+                         guide_stren=0, bounds=None, *, noise=None, seed=None, return_traj=True, use_graph=True,
+                         _reuse_host_buffers=False):
         """Reverse diffusion chain; same arguments and result dict as the reference.
 
         Extensions (keyword-only): ``noise=(eps, u)`` feeds host-chosen draws, eps (S,N,3) and u (S,N,C)
@@ -250,13 +252,34 @@ class ScorePosNet3D(nn.Module):
                 t_.record_stream(side)
         res = {"pos": out_pos, "v": out_v, "pos_uncond_traj": [], "v_uncond_traj": []}
         if return_traj:
-            host = {k: bufs[k].cpu() for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj")}
+            # one D2H copy per trajectory, through pinned staging buffers (the reference copies step by step, :671-681)
+            # (_reuse_host_buffers: private to shapemol_amd.sampling, which consumes the host tensors before the next call)
+            host = {k: self._to_host(bufs[k], k if _reuse_host_buffers else None) for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj")}
             res.update(pos_traj=list(host["pos_traj"].unbind(0)), v_traj=list(host["v_traj"].unbind(0)),
                        v0_traj=list(host["v0_traj"].unbind(0)), vt_traj=list(host["vt_traj"].unbind(0)),
                        pos_cond_traj=list(bufs["pos_cond_traj"].unbind(0)), v_cond_traj=list(bufs["v_cond_traj"].unbind(0)))
+            # not a key of the reference: the same trajectories as whole (S, N, ...) tensors, for callers that unbatch
+            # them at once (shapemol_amd.sampling) instead of re-stacking the per-step lists
+            res["_stacked"] = dict(host, pos_cond_traj=bufs["pos_cond_traj"], v_cond_traj=bufs["v_cond_traj"])
         else:
             res.update(pos_traj=[], v_traj=[], v0_traj=[], vt_traj=[], pos_cond_traj=[], v_cond_traj=[])
         return res
+
+    def _to_host(self, t, cache_key=None):
+        """Device tensor -> host tensor with one pinned-memory DMA (falls back to a pageable copy).  With a cache key the
+        pinned buffer is kept and handed out again by the next call of the same shape (pinning 1 GB costs as much as the copy)."""
+        cache = self.__dict__.setdefault("_pinned", {})
+        h = cache.get(cache_key) if cache_key is not None else None
+        if h is None or h.shape != t.shape or h.dtype != t.dtype:
+            try:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            except RuntimeError:
+                return t.cpu()
+            if cache_key is not None:
+                cache[cache_key] = h
+        h.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return h
 
     def _side_stream(self, dev):
         s = getattr(self, "_stream", None)

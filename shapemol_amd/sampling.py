@@ -1,0 +1,138 @@
+"""Sampling driver: the non-chemistry half of the reference's ``scripts/sample_diffusion.py``.
+
+What the reference script does around ``ScorePosNet3D.sample_diffusion`` for ONE shape condition
+(``scripts/sample_diffusion.py:47-162``): split ``num_samples`` into chunks of ``batch_size``, pick the atom count
+of every molecule (``sample_num_atoms`` = 'size': drawn by ``sample_func``; 'ref': the reference molecule's count),
+draw the initial coordinates (``torch.randn`` on the host, ``:79``) and atom types (``log_sample_categorical`` of
+uniform logits, ``:90-91``), run the chain, and unbatch final states and trajectories into per-molecule numpy
+arrays (``:111-157``).  This module reproduces that contract -- same arguments where they apply, same 9-tuple, same
+array layouts and dtypes, same ``result`` dict (``:279-290``) -- without the PyG ``data`` object: the caller passes
+the shape embedding (and, for ``pos_only``/'ref', the reference atom features) directly.
+
+The unbatching is the part worth doing differently on a GPU: the reference copies every trajectory entry to the
+host step by step (4-6 D2H copies per reverse step); here each trajectory crosses PCIe once, as one array, and is
+split on the host.
+"""
+import time
+from functools import partial
+
+import numpy as np
+import torch
+
+from .molopt_score_model import log_sample_categorical
+
+__all__ = ["atom_num_sampler", "sample_atom_nums", "sample_diffusion_ligand", "pack_result", "unbatch"]
+
+
+def sample_atom_nums(batch_size, atom_nums, atom_dist):
+    """``scripts/sample_diffusion.py:33-34``: numpy's global RNG, so ``np.random.seed`` governs it."""
+    return np.random.choice(atom_nums, batch_size, p=atom_dist).tolist()
+
+
+def atom_num_sampler(dists, voxel_shape, window=200):
+    """Atom-count prior of a shape condition (``scripts/sample_diffusion.py:245-253``): pool the histograms of all
+    voxel sizes within ``window`` of ``voxel_shape`` from ``MOSES2_training_val_shape_atomnum_dict.pkl``'s dict
+    (``{voxel_size: {num_atoms: count}}``; later keys overwrite earlier ones, as ``dict.update`` does there)."""
+    atom_nums = {}
+    for key in dists.keys():
+        if voxel_shape - window < key < voxel_shape + window:
+            atom_nums.update(dists[key])
+    keys = list(atom_nums.keys())
+    total = sum(atom_nums[k] for k in keys)
+    if total == 0:
+        raise ValueError("no atom-count statistics within the voxel-size window")
+    return partial(sample_atom_nums, atom_nums=keys, atom_dist=[atom_nums[k] / total for k in keys])
+
+
+def unbatch(stacked, cum_atoms, dtype=None):
+    """(S, N, ...) array -> list of (S, n_i, ...) arrays, one per molecule (reference layout
+    ``num_samples * [num_steps, num_atoms_i, ...]``, ``scripts/sample_diffusion.py:37-44,130-131``)."""
+    arr = np.asarray(stacked) if dtype is None else np.asarray(stacked).astype(dtype)
+    return [np.ascontiguousarray(arr[:, cum_atoms[k]:cum_atoms[k + 1]]) for k in range(len(cum_atoms) - 1)]
+
+
+def _traj_to_host(r, name):
+    """A whole trajectory of the result dict `r` as one host array (S, N, ...): the stacked tensor the accelerated
+    model hands out beside the reference's per-step lists, else the list stacked once."""
+    st = r.get("_stacked")
+    t = st[name] if st is not None and name in st else torch.stack(list(r[name]))
+    return t.cpu().numpy()
+
+
+def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device="cuda:0", num_steps=None,
+                            pos_only=False, center_pos_mode="none", sample_func=None, threshold_type=None,
+                            threshold_args=None, sample_num_atoms="prior", bounds=None, ref_num_atoms=None,
+                            ref_atom_feature=None, guide_stren=0, seed=None, use_graph=True):
+    """``sample_diffusion_ligand`` of the reference for one shape condition.
+
+    shape_emb        (32, 3) latent of the condition (``data.shape_emb``); repeated per molecule of a batch.
+    sample_num_atoms 'size' -> ``sample_func(n)`` gives the atom counts; 'ref' -> ``ref_num_atoms`` for every copy.
+    ref_atom_feature (ref_num_atoms,) int64, needed for ``pos_only`` (atom types are then kept, ``:84-86``).
+    bounds           accepted and ignored, like every caller of the reference's ``sample_diffusion`` with guidance off.
+    seed             seed of the device noise of the chains (None: drawn from torch's CPU generator per batch).
+
+    Returns the reference's 9-tuple: ``(pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj,
+    time_list, pred_pos_cond_traj, pred_v_cond_traj)``; positions are float64 host arrays, as there.
+    """
+    dev = torch.device(device)
+    shape_emb = torch.as_tensor(shape_emb, dtype=torch.float32).reshape(1, -1, 3)
+    all_pred_pos, all_pred_v = [], []
+    all_pred_pos_traj, all_pred_v_traj = [], []
+    all_pred_pos_cond_traj, all_pred_v_cond_traj = [], []
+    all_pred_v0_traj, all_pred_vt_traj = [], []
+    time_list = []
+    num_batch = int(np.ceil(num_samples / batch_size))
+    for i in range(num_batch):
+        n_data = batch_size if i < num_batch - 1 else num_samples - batch_size * (num_batch - 1)
+        t1 = time.time()
+        if sample_num_atoms == "size":
+            assert sample_func is not None
+            ligand_num_atoms = [int(x) for x in sample_func(n_data)]
+        elif sample_num_atoms == "ref":
+            assert ref_num_atoms is not None
+            ligand_num_atoms = [int(ref_num_atoms)] * n_data
+        else:
+            raise ValueError
+        batch_ligand = torch.repeat_interleave(torch.arange(n_data), torch.tensor(ligand_num_atoms)).to(dev)
+        all_ligand_atoms = sum(ligand_num_atoms)
+        init_ligand_pos = torch.randn(all_ligand_atoms, 3).to(dev)            # host generator, as the reference
+        if pos_only:
+            if sample_num_atoms != "ref" or ref_atom_feature is None:
+                raise ValueError("pos_only keeps the reference atom types: needs sample_num_atoms='ref' and ref_atom_feature")
+            init_ligand_v = torch.as_tensor(ref_atom_feature, dtype=torch.int64).repeat(n_data).to(dev)
+        else:
+            if getattr(model, "v_mode", "categorical") == "gaussian":
+                raise NotImplementedError("v_mode 'gaussian' is not part of the accelerated path")
+            uniform_logits = torch.zeros(len(batch_ligand), model.num_classes, device=dev)
+            init_ligand_v = log_sample_categorical(uniform_logits)
+        r = model.sample_diffusion(
+            init_ligand_pos=init_ligand_pos, init_ligand_v=init_ligand_v, batch_ligand=batch_ligand,
+            ligand_shape=shape_emb.repeat(n_data, 1, 1).to(dev).reshape(n_data, -1),
+            threshold_type=threshold_type, threshold_args=threshold_args, num_steps=num_steps,
+            center_pos_mode=center_pos_mode, guide_stren=guide_stren, bounds=bounds,
+            seed=None if seed is None else int(seed) + i, use_graph=use_graph,
+            **({"_reuse_host_buffers": True} if getattr(model, "_accelerated", False) else {}))
+        cum = np.cumsum([0] + ligand_num_atoms)
+        pos = r["pos"].cpu().numpy().astype(np.float64)
+        all_pred_pos += [pos[cum[k]:cum[k + 1]] for k in range(n_data)]
+        v = r["v"].cpu().numpy()
+        all_pred_v += [v[cum[k]:cum[k + 1]] for k in range(n_data)]
+        all_pred_pos_traj += unbatch(_traj_to_host(r, "pos_traj"), cum, np.float64)
+        all_pred_pos_cond_traj += unbatch(_traj_to_host(r, "pos_cond_traj"), cum, np.float64)
+        all_pred_v_traj += unbatch(_traj_to_host(r, "v_traj"), cum)
+        all_pred_v_cond_traj += unbatch(_traj_to_host(r, "v_cond_traj"), cum)
+        if not pos_only:
+            all_pred_v0_traj += unbatch(_traj_to_host(r, "v0_traj"), cum)
+            all_pred_vt_traj += unbatch(_traj_to_host(r, "vt_traj"), cum)
+        time_list.append(time.time() - t1)
+    return (all_pred_pos, all_pred_v, all_pred_pos_traj, all_pred_v_traj, all_pred_v0_traj, all_pred_vt_traj, time_list,
+            all_pred_pos_cond_traj, all_pred_v_cond_traj)
+
+
+def pack_result(data, outputs):
+    """The ``result`` dict the reference ``torch.save``s (``scripts/sample_diffusion.py:279-290``) and
+    ``scripts/evaluate_diffusion_sim.py:121-135`` reads."""
+    pred_pos, pred_v, pred_pos_traj, pred_v_traj, _v0, _vt, time_list, pred_pos_cond_traj, pred_v_cond_traj = outputs
+    return {"data": data, "pred_ligand_pos": pred_pos, "pred_ligand_v": pred_v, "pred_ligand_pos_traj": pred_pos_traj,
+            "pred_ligand_v_traj": pred_v_traj, "time": time_list, "pred_ligand_pos_cond_traj": pred_pos_cond_traj,
+            "pred_ligand_v_cond_traj": pred_v_cond_traj}

@@ -310,3 +310,39 @@ def test_error_reporting():
         m.sample_diffusion(torch.zeros(3, 3, device=DEV), torch.zeros(3, dtype=torch.long, device=DEV),
                            torch.zeros(3, dtype=torch.long, device=DEV), torch.zeros(1, 96, device=DEV),
                            num_steps=2, center_pos_mode="center")
+
+
+def test_sampling_driver_layout_and_equivalence():
+    """shapemol_amd.sampling.sample_diffusion_ligand (the reference driver's batching / init / unbatching contract):
+    result layout, dtypes, and that a batch equals the direct chain on the same initial state and noise seed."""
+    from shapemol_amd.sampling import pack_result, sample_diffusion_ligand
+    from shapemol_amd import log_sample_categorical
+    m = hip_model()
+    shape_emb = synth.synthetic_batch(1, seed=5)["shape"][0]
+    counts = iter([[9, 12], [7, 15], [11]])
+    steps = 12
+    torch.manual_seed(1234)
+    out = sample_diffusion_ligand(m, shape_emb, num_samples=5, batch_size=2, device=DEV, num_steps=steps,
+                                  sample_num_atoms="size", sample_func=lambda n: next(counts), seed=99)
+    pos, v, pos_traj, v_traj, v0_traj, vt_traj, times, pos_cond, v_cond = out
+    want = [9, 12, 7, 15, 11]
+    assert len(times) == 3 and [len(x) for x in (pos, v, pos_traj, v_traj, v0_traj, vt_traj, pos_cond, v_cond)] == [5] * 8
+    for k, n in enumerate(want):
+        assert pos[k].shape == (n, 3) and pos[k].dtype == np.float64
+        assert v[k].shape == (n,) and v[k].dtype == np.int64
+        assert pos_traj[k].shape == (steps, n, 3) and pos_traj[k].dtype == np.float64
+        assert v_traj[k].shape == (steps, n) and v0_traj[k].shape == (steps, n, 15) and vt_traj[k].shape == (steps, n, 15)
+        assert np.array_equal(pos_traj[k][-1], pos[k]) and np.array_equal(v_traj[k][-1], v[k])
+    res = pack_result({"id": 0}, out)
+    assert set(res) == {"data", "pred_ligand_pos", "pred_ligand_v", "pred_ligand_pos_traj", "pred_ligand_v_traj", "time",
+                        "pred_ligand_pos_cond_traj", "pred_ligand_v_cond_traj"}
+    # first batch again, by hand, in the driver's order of random draws
+    torch.manual_seed(1234)
+    batch = torch.repeat_interleave(torch.arange(2), torch.tensor([9, 12])).to(DEV)
+    p0 = torch.randn(21, 3).to(DEV)
+    v0 = log_sample_categorical(torch.zeros(21, 15, device=DEV))
+    sh = torch.as_tensor(shape_emb).reshape(1, -1).repeat(2, 1).to(DEV)
+    r = m.sample_diffusion(p0, v0, batch, sh, num_steps=steps, center_pos_mode="none", seed=99)
+    ref_pos = r["pos"].cpu().numpy().astype(np.float64)
+    assert np.array_equal(ref_pos[:9], pos[0]) and np.array_equal(ref_pos[9:], pos[1])
+    assert np.array_equal(r["v"].cpu().numpy()[:9], v[0])

@@ -121,3 +121,45 @@ def test_no_cpu_fallback():
         m.sample_diffusion(z(3, 3), z(3, dtype=torch.long), z(3, dtype=torch.long), z(1, 96), num_steps=2)
     with pytest.raises(RuntimeError):
         shapemol_amd.log_sample_categorical(z(3, 15))
+
+
+def test_driver_unbatch_matches_reference_loop_semantics():
+    """shapemol_amd.sampling.unbatch == the per-step / per-molecule append loop of the reference driver
+    (scripts/sample_diffusion.py:37-44,121-131), layouts and dtypes included."""
+    from shapemol_amd.sampling import unbatch
+    rs = np.random.RandomState(0)
+    counts = [3, 1, 5]
+    cum = np.cumsum([0] + counts)
+    steps, n = 4, sum(counts)
+    pos = rs.randn(steps, n, 3).astype(np.float32)
+    v = rs.randint(0, 15, size=(steps, n)).astype(np.int64)
+    ref_pos = [[] for _ in counts]
+    ref_v = [[] for _ in counts]
+    for s_ in range(steps):
+        p64 = pos[s_].astype(np.float64)
+        for k in range(len(counts)):
+            ref_pos[k].append(p64[cum[k]:cum[k + 1]])
+            ref_v[k].append(v[s_][cum[k]:cum[k + 1]])
+    ref_pos = [np.stack(x) for x in ref_pos]
+    ref_v = [np.stack(x) for x in ref_v]
+    got_pos, got_v = unbatch(pos, cum, np.float64), unbatch(v, cum)
+    for k in range(len(counts)):
+        assert got_pos[k].dtype == np.float64 and got_pos[k].shape == (steps, counts[k], 3)
+        assert got_v[k].dtype == np.int64 and got_v[k].shape == (steps, counts[k])
+        assert np.array_equal(got_pos[k], ref_pos[k]) and np.array_equal(got_v[k], ref_v[k])
+
+
+def test_driver_atom_count_prior_window():
+    """atom_num_sampler pools the histograms of voxel sizes strictly within +-200 of the condition's
+    (scripts/sample_diffusion.py:245-253), later keys overwriting earlier ones, and samples with numpy's global RNG."""
+    from shapemol_amd.sampling import atom_num_sampler
+    dists = {100: {10: 5, 11: 5}, 250: {11: 30, 12: 10}, 299: {20: 1}, 300: {30: 1000}, 900: {40: 1000}}
+    f = atom_num_sampler(dists, voxel_shape=100)            # keys 100, 250, 299 (300 is excluded: strict window)
+    assert f.keywords["atom_nums"] == [10, 11, 12, 20]
+    np.testing.assert_allclose(f.keywords["atom_dist"], np.array([5, 30, 10, 1]) / 46.0)
+    np.random.seed(3)
+    a = f(50)
+    np.random.seed(3)
+    assert a == f(50) and set(a) <= {10, 11, 12, 20} and len(a) == 50
+    with pytest.raises(ValueError):
+        atom_num_sampler(dists, voxel_shape=5000)
