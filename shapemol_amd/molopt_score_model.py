@@ -251,7 +251,12 @@ class ScorePosNet3D(nn.Module):
             if t_ is not None:
                 t_.record_stream(side)
         res = {"pos": out_pos, "v": out_v, "pos_uncond_traj": [], "v_uncond_traj": []}
-        if return_traj:
+        if return_traj and _reuse_host_buffers == "device":
+            # private to shapemol_amd.sampling: hand out the (S, N, ...) device buffers; the driver reorders them on the
+            # device and copies each to the host once
+            res.update(pos_traj=[], v_traj=[], v0_traj=[], vt_traj=[], pos_cond_traj=[], v_cond_traj=[])
+            res["_stacked"] = dict(bufs)
+        elif return_traj:
             # one D2H copy per trajectory, through pinned staging buffers (the reference copies step by step, :671-681)
             # (_reuse_host_buffers: private to shapemol_amd.sampling, which consumes the host tensors before the next call)
             host = {k: self._to_host(bufs[k], k if _reuse_host_buffers else None) for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj")}

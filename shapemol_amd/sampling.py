@@ -51,6 +51,37 @@ def unbatch(stacked, cum_atoms, dtype=None):
     return [np.ascontiguousarray(arr[:, cum_atoms[k]:cum_atoms[k + 1]]) for k in range(len(cum_atoms) - 1)]
 
 
+def _unbatch_on_device(t, counts, dtype=None):
+    """(S, N, ...) DEVICE tensor -> list of per-molecule host arrays (S, n_i, ...): rows are regrouped molecule by
+    molecule on the device (one index_copy), cross PCIe once into pinned memory, and the per-molecule arrays are
+    contiguous views of that one host array (no per-molecule copies)."""
+    S, N = t.shape[0], t.shape[1]
+    tail = tuple(t.shape[2:])
+    dev = t.device
+    cnt = torch.as_tensor(counts, dtype=torch.int64, device=dev)
+    cum = torch.cumsum(cnt, 0) - cnt                                   # first atom of each molecule
+    mol = torch.repeat_interleave(torch.arange(len(counts), device=dev), cnt)
+    local = torch.arange(N, device=dev) - cum[mol]
+    dest = (cum[mol] * S + local).unsqueeze(0) + torch.arange(S, device=dev).unsqueeze(1) * cnt[mol].unsqueeze(0)   # (S, N)
+    src = t.reshape(S * N, -1)
+    if dtype is not None:
+        src = src.to(dtype)
+    out = torch.empty_like(src)
+    out.index_copy_(0, dest.reshape(-1), src)
+    try:
+        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+    except RuntimeError:
+        host = out.cpu()
+    arr = host.numpy()
+    res, off = [], 0
+    for n in counts:
+        res.append(arr[off:off + S * n].reshape((S, n) + tail))
+        off += S * n
+    return res
+
+
 def _traj_to_host(r, name):
     """A whole trajectory of the result dict `r` as one host array (S, N, ...): the stacked tensor the accelerated
     model hands out beside the reference's per-step lists, else the list stacked once."""
@@ -111,19 +142,24 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
             threshold_type=threshold_type, threshold_args=threshold_args, num_steps=num_steps,
             center_pos_mode=center_pos_mode, guide_stren=guide_stren, bounds=bounds,
             seed=None if seed is None else int(seed) + i, use_graph=use_graph,
-            **({"_reuse_host_buffers": True} if getattr(model, "_accelerated", False) else {}))
+            **({"_reuse_host_buffers": "device"} if getattr(model, "_accelerated", False) else {}))
         cum = np.cumsum([0] + ligand_num_atoms)
         pos = r["pos"].cpu().numpy().astype(np.float64)
         all_pred_pos += [pos[cum[k]:cum[k + 1]] for k in range(n_data)]
         v = r["v"].cpu().numpy()
         all_pred_v += [v[cum[k]:cum[k + 1]] for k in range(n_data)]
-        all_pred_pos_traj += unbatch(_traj_to_host(r, "pos_traj"), cum, np.float64)
-        all_pred_pos_cond_traj += unbatch(_traj_to_host(r, "pos_cond_traj"), cum, np.float64)
-        all_pred_v_traj += unbatch(_traj_to_host(r, "v_traj"), cum)
-        all_pred_v_cond_traj += unbatch(_traj_to_host(r, "v_cond_traj"), cum)
+        st = r.get("_stacked")
+        if st is not None and all(torch.is_tensor(x) and x.is_cuda for x in st.values()):
+            take = lambda name, dt=None: _unbatch_on_device(st[name], ligand_num_atoms, dt)      # noqa: E731
+        else:
+            take = lambda name, dt=None: unbatch(_traj_to_host(r, name), cum, None if dt is None else np.float64)  # noqa: E731
+        all_pred_pos_traj += take("pos_traj", torch.float64)
+        all_pred_pos_cond_traj += take("pos_cond_traj", torch.float64)
+        all_pred_v_traj += take("v_traj")
+        all_pred_v_cond_traj += take("v_cond_traj")
         if not pos_only:
-            all_pred_v0_traj += unbatch(_traj_to_host(r, "v0_traj"), cum)
-            all_pred_vt_traj += unbatch(_traj_to_host(r, "vt_traj"), cum)
+            all_pred_v0_traj += take("v0_traj")
+            all_pred_vt_traj += take("vt_traj")
         time_list.append(time.time() - t1)
     return (all_pred_pos, all_pred_v, all_pred_pos_traj, all_pred_v_traj, all_pred_v0_traj, all_pred_vt_traj, time_list,
             all_pred_pos_cond_traj, all_pred_v_cond_traj)
