@@ -396,6 +396,8 @@ edge_fused_kernel(EdgeFusedArgs a) {
     constexpr int HD = H / 8;                                     // heads = VN channels
     // fused coordinate update (h2x): lane = (atom of the job, channel)
     double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);   // [nwave][32][2] behind the images
+    float *vn_o = reinterpret_cast<float *>(vn_red + nwave * 64) + wave * (APJ * 48);   // this wave's attention rows [APJ][16][3]
+    const bool one_job = njobs <= jstride;                                     // every wave has at most one job
     const int v_al = lane >> 4, v_c = lane & 15;
     const bool v_lane = H2X && v_al < APJ && v_c < HD;
     double v_s1 = 0.0, v_s2 = 0.0;
@@ -453,6 +455,12 @@ edge_fused_kernel(EdgeFusedArgs a) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
                     stg4(op + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
+                if (a.vn.enable && one_job) {           // keep the rows at hand for the VN-linear below (no L2 round trip)
+                    float *ol = vn_o + (n / SEGW) * 48 + 12 * g;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        stg4(ol + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
+                }
             }
         }
         job += jstride;
@@ -465,16 +473,25 @@ edge_fused_kernel(EdgeFusedArgs a) {
         if (!a.vn.enable) return;
         // ---- VN-linear of this wave's atoms: p, d per channel from the 16 attention rows (+ x, + shape term);
         //      lane = (atom of the job, channel).  The rows were stored by this wave above (same CU, write-through).
-        __syncthreads();
+        if (!one_job) __syncthreads();               // rows come back through L2: drain this workgroup's stores first
         for (int jb = job0; jb < njobs; jb += jstride) {
             const int va = jb * APJ + v_al;
             if (v_lane && va < a.n_atoms) {
-                const float *ov = a.out + (size_t)va * 48;
                 float orow[48];
+                if (one_job) {
+                    const float *ov = vn_o + v_al * 48;
 #pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    const float4 t = ldg4(ov + 4 * i);
-                    orow[4 * i] = t.x; orow[4 * i + 1] = t.y; orow[4 * i + 2] = t.z; orow[4 * i + 3] = t.w;
+                    for (int i = 0; i < 12; ++i) {
+                        const float4 t = ldg4(ov + 4 * i);
+                        orow[4 * i] = t.x; orow[4 * i + 1] = t.y; orow[4 * i + 2] = t.z; orow[4 * i + 3] = t.w;
+                    }
+                } else {
+                    const float *ov = a.out + (size_t)va * 48;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        const float4 t = ldg4(ov + 4 * i);
+                        orow[4 * i] = t.x; orow[4 * i + 1] = t.y; orow[4 * i + 2] = t.z; orow[4 * i + 3] = t.w;
+                    }
                 }
                 float wf[16], wd[16];
 #pragma unroll
