@@ -398,9 +398,6 @@ edge_fused_kernel(EdgeFusedArgs a) {
     double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);   // [nwave][32][2] behind the images
     float *vn_o = reinterpret_cast<float *>(vn_red + nwave * 64) + wave * (APJ * 48);   // this wave's attention rows [APJ][16][3]
     const bool one_job = njobs <= jstride;                                     // every wave has at most one job
-    const int v_al = lane >> 4, v_c = lane & 15;
-    const bool v_lane = H2X && v_al < APJ && v_c < HD;
-    double v_s1 = 0.0, v_s2 = 0.0;
     while (have) {
         asm volatile("" ::: "memory");
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
@@ -471,6 +468,9 @@ edge_fused_kernel(EdgeFusedArgs a) {
 
     if constexpr (H2X) {
         if (!a.vn.enable) return;
+        const int v_al = lane >> 4, v_c = lane & 15;               // lane = (atom of the job, channel)
+        const bool v_lane = v_al < APJ && v_c < HD;
+        double v_s1 = 0.0, v_s2 = 0.0;
         // ---- VN-linear of this wave's atoms: p, d per channel from the 16 attention rows (+ x, + shape term);
         //      lane = (atom of the job, channel).  The rows were stored by this wave above (same CU, write-through).
         if (!one_job) __syncthreads();               // rows come back through L2: drain this workgroup's stores first
