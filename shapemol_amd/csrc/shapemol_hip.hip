@@ -430,8 +430,10 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_VX>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_VH>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, 1>::TOTAL * 4));
 #define SETATTR3(K)                                                                                                   \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4 + 12 * (512 + 96 * 4)));
+    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4 + 12 * (512 + 96 * 4))); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4 + 12 * (512 + 96 * 4)));
     HIPCHK(hipFuncSetAttribute((const void *)node_prologue6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * Chain6Lds<H>::FRAG * 16 + Chain6Lds<H>::PRE * 4)));
     HIPCHK(hipFuncSetAttribute((const void *)node_chain6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain6Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin6Chunk * 3 * H * 32));
@@ -485,8 +487,14 @@ int launch_fused(shapemol_ctx *c, hipStream_t s, const EdgeFusedArgs &a) {
     const size_t shm = (EdgePhaseImage<H, H / 16>::TOTAL + (H2X ? EdgePhaseImage<H, 1>::TOTAL : 0)) * sizeof(float)
                        + (H2X ? (size_t)waves * (32 * 2 * 8 + apj * 48 * 4) : 0);   // + reduction scratch and attention rows of the fused coordinate update
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
-    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
-    else LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    const bool one = njobs <= grid * waves;      // every wave has at most one job: straight-line instantiation
+    if (KP == 8) {
+        if (one) LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 8, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
+        else LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+    } else {
+        if (one) LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 16, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
+        else LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+    }
     return 0;
 }
 

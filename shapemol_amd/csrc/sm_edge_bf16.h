@@ -257,7 +257,9 @@ struct EdgeFusedArgs {
 };
 constexpr int kVnReplicas = 16;
 
-template <int H, int KP, bool H2X>
+// ONE = true: the launch gives every wave at most one job (jobs <= workgroups x waves; the common case up to ~6k atoms):
+// the job loops become straight-line code and no next job's rows are kept in flight (fewer live registers).
+template <int H, int KP, bool H2X, bool ONE = false>
 __global__ void __launch_bounds__(768)
 edge_fused_kernel(EdgeFusedArgs a) {
     static_assert(KP == 8 || KP == 16, "single-tile jobs");
@@ -324,7 +326,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
     if (SM_ABL(10)) have = false;
 
     // ---- key phase ---------------------------------------------------------------------------------
-    while (have) {
+    while (have) {   // (a single pass when ONE)
         asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         float rb[5];
@@ -373,6 +375,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
             }
         }
         SM_TICK(a.stamps, 6);
+        if constexpr (ONE) break;
         job += jstride;
         have = job < njobs;
         asm volatile("" ::: "memory");       // keep the next job's loads below this job's tail (register pressure)
@@ -460,6 +463,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
                 }
             }
         }
+        if constexpr (ONE) break;
         job += jstride;
         have = job < njobs;
         asm volatile("" ::: "memory");
