@@ -219,14 +219,29 @@ size_t pack_phase_image(Image &im, const Mlp &m, int kv_in, bool perm_heads) {
     constexpr int NT = H / 16, NB = NT / 2;
     const int nt2 = perm_heads ? 1 : NT;
     const int G4 = (NT + 3) / 4;
-    const int o_wr = 0, o_g = o_wr + 5 * G4 * 256, o_b = o_g + H, o_b2 = o_b + H, o_w2 = o_b2 + nt2 * 16;
+    const bool bf1 = nt2 > 1;          // EdgePhaseImage::BF1
+    const int o_wr = 0, o_g = o_wr + (bf1 ? 3 * NT * 256 : 5 * G4 * 256), o_b = o_g + H, o_b2 = o_b + H, o_w2 = o_b2 + nt2 * 16;
     const int total = o_w2 + 3 * nt2 * NB * 256;
     const size_t o = im.alloc(total);
     float *d = &im.d[o];
     for (int t = 0; t < NT; ++t)
         for (int s = 0; s < 5; ++s)
             for (int lane = 0; lane < 64; ++lane)
-                d[o_wr + ((s * G4 + t / 4) * 64 + lane) * 4 + (t & 3)] = m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * s + (lane >> 4)];
+                if (!bf1) d[o_wr + ((s * G4 + t / 4) * 64 + lane) * 4 + (t & 3)] = m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * s + (lane >> 4)];
+    if (bf1) {
+        uint32_t *wr = reinterpret_cast<uint32_t *>(d + o_wr);
+        for (int t = 0; t < NT; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int q = 0; q < 4; ++q) {
+                    uint16_t pc[2][3];
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * q + e;
+                        split3_host(j < 5 ? m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * j + (lane >> 4)] : 0.f, pc[e]);
+                    }
+                    for (int piece = 0; piece < 3; ++piece)
+                        wr[((size_t)(piece * NT + t) * 64 + lane) * 4 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+                }
+    }
     std::memcpy(d + o_g, m.g, H * sizeof(float));
     std::memcpy(d + o_b, m.be, H * sizeof(float));
     for (int i = 0; i < nt2 * 16; ++i) {

@@ -44,9 +44,13 @@ template <int H, int NT2>
 struct EdgePhaseImage {
     static constexpr int NT = H / 16, NB = NT / 2;
     static constexpr int G4 = (NT + 3) / 4;             // groups of four output tiles
-    static constexpr int O_WR = 0;                      // [5][G4][64][4] fp32 A fragments of W1[:, 0:20]: one 16-byte
-                                                        // LDS read feeds k-step s of tiles 4h .. 4h+3
-    static constexpr int O_G = O_WR + 5 * G4 * 256;     // gamma[H]
+    static constexpr bool BF1 = NT2 > 1;                // first Linear's RBF block also on the bf16 matrix cores (the
+                                                        // heads-wide value MLP of h2x keeps fp32: both images share LDS)
+    static constexpr int O_WR = 0;                      // BF1: 3 pieces x [NT][64][4] u32, K = 20 padded to 32: element j of
+                                                        //      lane (m, g) = piece(W1[16t + m][4j + g]) for j < 5, else 0
+                                                        // else [5][G4][64][4] fp32 A fragments of W1[:, 0:20]: one 16-byte
+                                                        //      LDS read feeds k-step s of tiles 4h .. 4h+3
+    static constexpr int O_G = O_WR + (BF1 ? 3 * NT * 256 : 5 * G4 * 256);     // gamma[H]
     static constexpr int O_B = O_G + H;                 // beta[H]
     static constexpr int O_B2 = O_B + H;                // b2[NT2 * 16]
     static constexpr int O_W2 = O_B2 + NT2 * 16;        // 3 pieces x [NT2][NB][64][4] u32 (two bf16 each)
@@ -78,6 +82,40 @@ SM_DEV void first_linear_rbf(const float *wr, const float (&rb)[5], f32x4 (&acc)
 #pragma unroll
         for (int h = 0; h < G4; ++h) cur[h] = nxt[h];
     }
+}
+
+// The same product with exactly split operands on the bf16 matrix cores: one K = 32 step (20 centres + padding),
+// six piece products per tile; overlaps with vector work, which the fp32 MFMA does not.
+template <int NT>
+SM_DEV void first_linear_rbf_bf16(const float *wr, const float (&rb)[5], f32x4 (&acc)[NT], int lane) {
+    const unsigned *w = reinterpret_cast<const unsigned *>(wr);
+    u32x4 bh = {0u, 0u, 0u, 0u}, bm = {0u, 0u, 0u, 0u}, bl = {0u, 0u, 0u, 0u};
+    {
+        unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2;
+        split3_pair(rb[0], rb[1], h0, m0, l0);
+        split3_pair(rb[2], rb[3], h1, m1, l1);
+        split3_pair(rb[4], 0.f, h2, m2, l2);
+        bh[0] = h0; bh[1] = h1; bh[2] = h2; bm[0] = m0; bm[1] = m1; bm[2] = m2; bl[0] = l0; bl[1] = l1; bl[2] = l2;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const u32x4 ah = *reinterpret_cast<const u32x4 *>(w + ((0 * NT + t) * 64 + lane) * 4);
+        const u32x4 am = *reinterpret_cast<const u32x4 *>(w + ((1 * NT + t) * 64 + lane) * 4);
+        const u32x4 al = *reinterpret_cast<const u32x4 *>(w + ((2 * NT + t) * 64 + lane) * 4);
+        f32x4 c = acc[t];
+        c = mfma_bf16(al, bh, c);
+        c = mfma_bf16(am, bm, c);
+        c = mfma_bf16(ah, bl, c);
+        c = mfma_bf16(am, bh, c);
+        c = mfma_bf16(ah, bm, c);
+        c = mfma_bf16(ah, bh, c);
+        acc[t] = c;
+    }
+}
+template <class IM, int NT>
+SM_DEV void first_linear_of(const float *img, const float (&rb)[5], f32x4 (&acc)[NT], int lane) {
+    if constexpr (IM::BF1) first_linear_rbf_bf16<NT>(img + IM::O_WR, rb, acc, lane);
+    else first_linear_rbf<NT>(img + IM::O_WR, rb, acc, lane);
 }
 
 template <int H, int KP, int MODE>
@@ -148,7 +186,7 @@ edge_phase_kernel(EdgePhaseArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
-            first_linear_rbf<NT>(lds + IM::O_WR, rb, acc, lane);
+            first_linear_of<IM, NT>(lds, rb, acc, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
@@ -299,20 +337,21 @@ edge_fused_kernel(EdgeFusedArgs a) {
         for (int t = 0; t < NT; ++t) { ga[t] = ldg4(pi + 16 * t + 4 * g); gb[t] = ldg4(pj + 16 * t + 4 * g); }
     };
     // hidden = ReLU(LN(A_i + B_j + W_r rbf)) with the image at `img`
-    auto hidden = [&](const float *img, const float (&rb)[5], float (&hid)[NT * 4], bool tick) {
+    auto hidden = [&](auto im_tag, const float *img, const float (&rb)[5], float (&hid)[NT * 4], bool tick) {
+        using IM = decltype(im_tag);
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
         if (tick) SM_TICK(a.stamps, 2);
-        first_linear_rbf<NT>(img + IMK::O_WR, rb, acc, lane);
+        first_linear_of<IM, NT>(img, rb, acc, lane);
         if (tick) SM_TICK(a.stamps, 3);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
             hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
         }
-        ln_relu_dlayout<NT>(hid, img + IMK::O_G, img + IMK::O_B, g);
+        ln_relu_dlayout<NT>(hid, img + IM::O_G, img + IM::O_B, g);
     };
 
     int job = job0;
@@ -326,13 +365,16 @@ edge_fused_kernel(EdgeFusedArgs a) {
     if (SM_ABL(10)) have = false;
 
     // ---- key phase ---------------------------------------------------------------------------------
+    bool first = true;
     while (have) {   // (a single pass when ONE)
         asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
+        if (!first) issue_loads(job, 0, H);          // later jobs: rows requested here, not a job ahead (68 registers less across the body)
+        first = false;
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         float rb[5];
         rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), cen, rb);
         float hid[NT * 4];
-        hidden(lds, rb, hid, true);
+        hidden(IMK{}, lds, rb, hid, true);
         SM_TICK(a.stamps, 4);
         // second Linear one pair of head blocks (t, t + NT/2) at a time, software-pipelined: the logits and
         // softmax of a finished pair are independent vector work placed under the next pair's MFMAs
@@ -378,8 +420,6 @@ edge_fused_kernel(EdgeFusedArgs a) {
         if constexpr (ONE) break;
         job += jstride;
         have = job < njobs;
-        asm volatile("" ::: "memory");       // keep the next job's loads below this job's tail (register pressure)
-        if (have) issue_loads(job, 0, H);
     }
 
     // ---- hand-over: value-phase loads of the first job fly across the weight swap ------------------
@@ -401,8 +441,11 @@ edge_fused_kernel(EdgeFusedArgs a) {
     double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);   // [nwave][32][2] behind the images
     float *vn_o = reinterpret_cast<float *>(vn_red + nwave * 64) + wave * (APJ * 48);   // this wave's attention rows [APJ][16][3]
     const bool one_job = njobs <= jstride;                                     // every wave has at most one job
+    first = true;
     while (have) {
         asm volatile("" ::: "memory");
+        if (!first) issue_loads(job, 2 * H, 3 * H);
+        first = false;
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         float rb[5];
         rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), cen, rb);
@@ -417,7 +460,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
             for (int r = 0; r < NT; ++r) al[r] = r < NT / 2 ? ap[(NT / 2) * (g & 1) + r] : 0.f;
         }
         float hid[NT * 4];
-        hidden(imv, rb, hid, false);
+        hidden(IMV{}, imv, rb, hid, false);
         u32x4 bh[NT / 2], bm[NT / 2], bl[NT / 2];
         split_act<NT>(hid, bh, bm, bl);
         const unsigned *w2v = reinterpret_cast<const unsigned *>(imv) + IMV::O_W2;
@@ -466,8 +509,6 @@ edge_fused_kernel(EdgeFusedArgs a) {
         if constexpr (ONE) break;
         job += jstride;
         have = job < njobs;
-        asm volatile("" ::: "memory");
-        if (have) issue_loads(job, 2 * H, 3 * H);
     }
 
     if constexpr (H2X) {
