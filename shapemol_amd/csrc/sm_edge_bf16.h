@@ -297,8 +297,11 @@ constexpr int kVnReplicas = 16;
 
 // ONE = true: the launch gives every wave at most one job (jobs <= workgroups x waves; the common case up to ~6k atoms):
 // the job loops become straight-line code and no next job's rows are kept in flight (fewer live registers).
+// amdgpu_waves_per_eu(3, 3): the launch never has more than three waves per SIMD (<= 12 per workgroup, one workgroup per
+// CU), so the register allocator may use the whole 168-VGPR budget instead of aiming at four waves (128): the
+// single-job instantiation then takes 138 registers and schedules its LDS reads further ahead (+4 % on the step).
 template <int H, int KP, bool H2X, bool ONE = false>
-__global__ void __launch_bounds__(768)
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
 edge_fused_kernel(EdgeFusedArgs a) {
     static_assert(KP == 8 || KP == 16, "single-tile jobs");
     constexpr int NT = H / 16;
@@ -367,7 +370,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
     // ---- key phase ---------------------------------------------------------------------------------
     bool first = true;
     while (have) {   // (a single pass when ONE)
-        asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
+        if constexpr (!ONE) asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
         if (!first) issue_loads(job, 0, H);          // later jobs: rows requested here, not a job ahead (68 registers less across the body)
         first = false;
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
@@ -443,7 +446,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
     const bool one_job = njobs <= jstride;                                     // every wave has at most one job
     first = true;
     while (have) {
-        asm volatile("" ::: "memory");
+        if constexpr (!ONE) asm volatile("" ::: "memory");
         if (!first) issue_loads(job, 2 * H, 3 * H);
         first = false;
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
