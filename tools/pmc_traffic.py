@@ -2,7 +2,7 @@
 """Per-kernel-class HBM traffic from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE):
     python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> > pmc_traffic.json
 Counters are in KB per dispatch (summed over the XCDs by rocprofv3); mean per launch per class."""
-import collections, csv, json, sys
+import collections, csv, json, re, sys
 
 CLASSES = [("edge_fused_kernel", "false", "edge_x2h"), ("edge_fused_kernel", "true", "edge_h2x"),
            ("node_chain6_kernel", "", "node_chain"), ("node_chain_kernel", "", "node_chain"),
@@ -13,8 +13,11 @@ CLASSES = [("edge_fused_kernel", "false", "edge_x2h"), ("edge_fused_kernel", "tr
 
 
 def classify(name):
+    m = re.search(r"edge_fused_kernel<\d+, \d+, (false|true)", name)      # third template argument: H2X
+    if m:
+        return "edge_h2x" if m.group(1) == "true" else "edge_x2h"
     for key, flag, cls in CLASSES:
-        if key in name and (not flag or name.rstrip(">) ").split("(")[0].rstrip(">").endswith(flag)):
+        if key in name and not flag:
             return cls
     return None
 
