@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SHAPEMOL_ABI_VERSION 1
+#define SHAPEMOL_ABI_VERSION 2
 
 typedef struct shapemol_ctx shapemol_ctx;
 
@@ -93,13 +93,24 @@ typedef struct shapemol_traj {
  *   u (S,N,C) ~ U[0,1), consumed per step in the reference's order (randn_like then rand_like,
  *   models/molopt_score_model.py:662,99).  Otherwise noise is generated on the device
  *   (Philox4x32-10 keyed by `seed`, Box-Muller).
- *   out_pos (N,3) f32, out_v (N,) i64: final state.  use_graph != 0 replays one captured
- *   hipGraph per step. */
+ *   out_pos (N,3) f32, out_v (N,) i64: final state.  use_graph != 0 replays a captured hipGraph of one
+ *   reverse step (and of eight steps back to back).  The capture depends on (n_atoms, n_mols) only: seed,
+ *   noise and trajectory pointers are passed through device memory, so chains with new seeds or new result
+ *   buffers replay the same executable. */
 int shapemol_sample(shapemol_ctx *ctx, const float *d_init_pos, const int64_t *d_init_v,
                     const int64_t *d_batch, int64_t n_atoms, int64_t n_mols, const float *d_shape,
                     int32_t num_steps, const float *d_eps, const float *d_u, uint64_t seed,
                     const shapemol_traj *traj, float *out_pos, int64_t *out_v,
                     int32_t use_graph, void *stream);
+
+/* Input validation happens on the device (no host synchronisation in _score/_sample): an unsorted or
+ * out-of-range d_batch, an atom type outside [0, num_classes) or a time step outside [0, num_timesteps)
+ * sets a sticky flag (the offending index is clamped, so nothing is read or written out of bounds).
+ * shapemol_status synchronises the device and returns non-zero (message in shapemol_last_error) if the
+ * last _score/_sample on this context saw such an input or a timed-out grid barrier (vn_fuse = 1);
+ * flags_out (may be NULL) receives the eight raw flags {barrier, batch, atom type, time step, 0...}.
+ * The reference raises from the corresponding torch indexing ops (models/molopt_score_model.py:292-301). */
+int shapemol_status(shapemol_ctx *ctx, int32_t *flags_out);
 
 /* argmax_c( logits[n,c] - log(-log(u[n,c] + 1e-30) + 1e-30) ); d_u NULL -> device Philox(seed). */
 int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, const float *d_u,

@@ -11,13 +11,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SHAPEMOL_LIB selects a diagnostic build (tools/ only), e.g. "stamps" or "abl1"
 _variant = os.environ.get("SHAPEMOL_LIB") or ("stamps" if os.environ.get("SHAPEMOL_STAMPS") == "1" else "")
 LIB_PATH = os.path.join(_HERE, f"libshapemol_hip_{_variant}.so" if _variant else "libshapemol_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = (
     "shapemol_abi_version", "shapemol_last_error", "shapemol_weight_count", "shapemol_create",
     "shapemol_destroy", "shapemol_reserve", "shapemol_score", "shapemol_sample",
     "shapemol_log_sample_categorical", "shapemol_set_option", "shapemol_debug_read",
-    "shapemol_profile_begin", "shapemol_profile_end",
+    "shapemol_profile_begin", "shapemol_profile_end", "shapemol_status",
 )
 
 
@@ -78,6 +78,7 @@ def load():
     lib.shapemol_set_option.argtypes = [vp, C.c_char_p, i64]
     lib.shapemol_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     lib.shapemol_debug_read.restype = i64
+    lib.shapemol_status.argtypes = [vp, vp]
     lib.shapemol_profile_begin.argtypes = [vp]
     lib.shapemol_profile_end.argtypes = [vp, vp, vp, vp, C.c_int]
     if lib.shapemol_abi_version() != ABI_VERSION:

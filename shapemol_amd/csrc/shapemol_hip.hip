@@ -290,16 +290,17 @@ size_t pack_linear6_image(Image &im, size_t src, int rows, int K) {
 }
 
 template <int H>
-void build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D) {
+int build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D) {
     const int G = c.num_r_gaussian, SL = c.shape_latent_dim, S = c.shape_dim, hd = c.n_heads;
     const int kv = G + 2 * H + SL, cin = 1 + hd + S, NT = H / 16;
+    bool contiguous = true;
     auto put_pre = [&](const Mlp &k, const Mlp &v) {      // 4 images of [H][H]: k_i, k_j, v_i, v_j column blocks
         const Mlp *src[4] = {&k, &k, &v, &v};
         size_t first = 0;
         for (int blk = 0; blk < 4; ++blk) {
             const size_t o = pack_image(im, src[blk]->l1.w, H, H, H, kv, G + (blk & 1) * H);
             if (blk == 0) first = o;
-            else if (o != first + (size_t)blk * H * H) std::abort();     // images must be contiguous
+            else if (o != first + (size_t)blk * H * H) contiguous = false;     // images must be contiguous
         }
         return first;
     };
@@ -309,6 +310,7 @@ void build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, 
         return o;
     };
     D.pre_x2h = put_pre(L.hk, L.hv); D.pre_h2x = put_pre(L.xk, L.xv);
+    if (!contiguous) return fail("shapemol_create: packed first-layer images are not contiguous (H * H must be a multiple of 64)");
     D.sk_x2h = put_scols(L.hk); D.sv_x2h = put_scols(L.hv); D.sk_h2x = put_scols(L.xk); D.sv_h2x = put_scols(L.xv);
     D.bk_x2h = im.put(L.hk.l1.b, H); D.bv_x2h = im.put(L.hv.l1.b, H);
     D.bk_h2x = im.put(L.xk.l1.b, H); D.bv_h2x = im.put(L.xv.l1.b, H);
@@ -339,6 +341,7 @@ void build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, 
             im.d[D.wd_o + ch * 16 + m] = hh < 0 ? 0.f : L.vn_d[(size_t)ch * cin + 1 + hh];
         }
     }
+    return 0;
 }
 
 struct ProfRec { const char *name; hipEvent_t e0, e1; };
@@ -366,6 +369,8 @@ struct shapemol_ctx {
     int kstamp_sel = -1;                    // which launch: 0 node_pre, 1 edge_x2h, 2 edge_h2x (layer 0)
     int stamp_on = 0;
     double *bn_acc = nullptr;
+    int *status = nullptr;                  // [8] sticky error flags (StatusFlag), cleared at the start of _score/_sample
+    ChainParams *chain_params = nullptr;    // per-chain parameters read by the posterior-step kernel
     // last evaluation (debug_read)
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
@@ -377,7 +382,14 @@ struct shapemol_ctx {
     std::vector<ProfRec> prof;
     // graph cache
     hipGraphExec_t gexec = nullptr, gexec_u = nullptr;     // one step / kGraphUnroll steps
-    struct GraphKey { int64_t N, B; const void *eps, *u, *tp[6]; uint64_t seed; int steps; bool operator==(const GraphKey &o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; } } gkey{};
+    // the captured step depends on the batch geometry only: seed, noise and trajectory pointers live in chain_params
+    struct GraphKey { int64_t N = 0, B = 0; bool operator==(const GraphKey &o) const { return N == o.N && B == o.B; } } gkey{};
+    void drop_graphs() {      // a replay may still be in flight: drain the device before destroying the executables
+        if (!gexec && !gexec_u) return;
+        hipDeviceSynchronize();
+        if (gexec) { hipGraphExecDestroy(gexec); gexec = nullptr; }
+        if (gexec_u) { hipGraphExecDestroy(gexec_u); gexec_u = nullptr; }
+    }
     const float *P(size_t off) const { return d_img + off; }
 };
 
@@ -406,8 +418,7 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
     HIPCHK(hipDeviceSynchronize());
     for (void *p : c->allocs) hipFree(p);
     c->allocs.clear();
-    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-    if (c->gexec_u) { hipGraphExecDestroy(c->gexec_u); c->gexec_u = nullptr; }
+    c->drop_graphs();
     const int64_t capN = std::max<int64_t>(N, c->capN), capB = std::max<int64_t>(B, c->capB);
     const shapemol_config &g = c->cfg;
     const int H = g.hidden_dim, L = g.num_layers, hd = g.n_heads;
@@ -425,7 +436,8 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
         A(&c->h_a, capN * H) || A(&c->h_b, capN * H) || A(&c->pre0, capN * 4 * H) || A(&c->preAB, capN * 8 * H) || A(&c->q_x, capN * H) || A(&c->q_h, capN * H) ||
         A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->alpha, capN * c->KP * 2 * (H / 16)) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
         A(&c->x_b, capN * 3) || A(&c->x_state, capN * 3) || A(&c->pred_pos, capN * 3) ||
-        A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * kBnReplicas * 2 * hd + L + 1))
+        A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * kBnReplicas * 2 * hd + L + 1) ||
+        A(&c->status, 8) || A(&c->chain_params, 1))
         return 1;
     c->capN = capN; c->capB = capB;
     return 0;
@@ -447,8 +459,8 @@ int set_edge_attr(int KP) {
 #define SETATTR3(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4 + 12 * (512 + 96 * 4))); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4 + 12 * (512 + 96 * 4)));
+    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgePhaseImage<H, H / 16>::TOTAL + EdgePhaseImage<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
     HIPCHK(hipFuncSetAttribute((const void *)node_prologue6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * Chain6Lds<H>::FRAG * 16 + Chain6Lds<H>::PRE * 4)));
     HIPCHK(hipFuncSetAttribute((const void *)node_chain6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain6Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin6Chunk * 3 * H * 32));
@@ -500,7 +512,7 @@ int launch_fused(shapemol_ctx *c, hipStream_t s, const EdgeFusedArgs &a) {
     const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
     const size_t shm = (EdgePhaseImage<H, H / 16>::TOTAL + (H2X ? EdgePhaseImage<H, 1>::TOTAL : 0)) * sizeof(float)
-                       + (H2X ? (size_t)waves * (32 * 2 * 8 + apj * 48 * 4) : 0);   // + reduction scratch and attention rows of the fused coordinate update
+                       + (H2X ? (size_t)vn_red_doubles(waves, H / 8) * 8 + (size_t)waves * apj * 48 * 4 : 0);   // + reduction scratch and attention rows of the fused coordinate update
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
     const bool one = njobs <= grid * waves;      // every wave has at most one job: straight-line instantiation
     if (KP == 8) {
@@ -556,7 +568,7 @@ template <int H>
 int run_prep(shapemol_ctx *c, hipStream_t s, const int64_t *d_batch, int64_t N, int64_t B, const float *d_shape) {
     const shapemol_config &g = c->cfg;
     const int L = g.num_layers, hd = g.n_heads, SL = g.shape_latent_dim, S = g.shape_dim;
-    LAUNCH("prep", hipLaunchKernelGGL(mol_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_batch, (int)N, (int)B, c->mol_of, c->mol_off));
+    LAUNCH("prep", hipLaunchKernelGGL(mol_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_batch, (int)N, (int)B, c->mol_of, c->mol_off, c->status));
     ShapeInvArgs si{d_shape, c->P(c->dm.inv.w1), c->P(c->dm.inv.b1), c->P(c->dm.inv.g), c->P(c->dm.inv.be),
                     c->P(c->dm.inv.w2), c->P(c->dm.inv.b2), c->inv, S, SL};
     LAUNCH("prep", hipLaunchKernelGGL(shape_invariant_kernel, dim3(B), dim3(64), 0, s, si));
@@ -674,7 +686,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                 double *tail = c->bn_acc + (size_t)L * kBnReplicas * 2 * hd;
                 fa.vn = {c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o), c->P(Dl.wd_o),
                          c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd,
-                         reinterpret_cast<unsigned *>(tail + l), reinterpret_cast<int *>(tail + L), x_next, c->vn_fuse == 1 ? 1 : 2};
+                         reinterpret_cast<unsigned *>(tail + l), c->status + ST_VN_BARRIER, x_next, c->vn_fuse == 1 ? 1 : 2};
                 if (c->vn_fuse == 1) vn_done = true; else stats_done = true;
             }
             if (launch_fused<H, true>(c, s, fa)) return 1;
@@ -706,18 +718,15 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
 }
 
 template <int H>
-int run_ddpm(shapemol_ctx *c, hipStream_t s, int64_t N, const float *d_eps, const float *d_u, uint64_t seed,
-             const shapemol_traj *tr) {
+int run_ddpm(shapemol_ctx *c, hipStream_t s, int64_t N) {
     const shapemol_config &g = c->cfg;
     DdpmArgs a{};
     a.pred_pos = c->pred_pos; a.pred_v = c->pred_v; a.x_t = c->x_state; a.v_t = c->v_state; a.mol_of = c->mol_of;
     a.t_first = c->cfg.num_timesteps - 1;
     a.c0 = c->P(c->dm.tab[0]); a.ct = c->P(c->dm.tab[1]); a.logvar = c->P(c->dm.tab[2]); a.log_a = c->P(c->dm.tab[3]);
     a.log_1ma = c->P(c->dm.tab[4]); a.log_abar = c->P(c->dm.tab[5]); a.log_1mabar = c->P(c->dm.tab[6]);
-    a.eps = d_eps; a.u = d_u; a.step_cur = c->steps + 1; a.step_ptr = c->steps; a.seed = seed;
+    a.cp = c->chain_params; a.step_cur = c->steps + 1; a.step_ptr = c->steps;
     a.x_next = c->x_state; a.v_next = c->v_state;
-    if (tr) { a.tr_pos = tr->pos_traj; a.tr_v = tr->v_traj; a.tr_v0 = tr->v0_traj; a.tr_vt = tr->vt_traj;
-              a.tr_pos_cond = tr->pos_cond_traj; a.tr_v_cond = tr->v_cond_traj; }
     a.n_atoms = (int)N; a.C = g.num_classes;
     if (c->stamp_on) LAUNCH("stamp", hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(64), 0, s, c->stamps, c->steps + 1, 1024));
     if (g.num_classes <= 16) LAUNCH("ddpm", hipLaunchKernelGGL(ddpm_step16_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, s, a));
@@ -792,8 +801,8 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
     }
     dm.layer.resize(cfg->num_layers);
     for (int l = 0; l < cfg->num_layers; ++l) {
-        if (H == 128) build_layer_image<128>(*cfg, hm.layer[l], im, dm.layer[l]);
-        else build_layer_image<32>(*cfg, hm.layer[l], im, dm.layer[l]);
+        if (H == 128 ? build_layer_image<128>(*cfg, hm.layer[l], im, dm.layer[l])
+                     : build_layer_image<32>(*cfg, hm.layer[l], im, dm.layer[l])) { delete c; return 1; }
     }
     for (int l = 0; l < cfg->num_layers; ++l) {      // paired images: pre_h2x(l) | pre_x2h(l + 1)
         const size_t blk = (size_t)4 * H * H;
@@ -824,8 +833,7 @@ void shapemol_destroy(shapemol_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    if (c->gexec) hipGraphExecDestroy(c->gexec);
-    if (c->gexec_u) hipGraphExecDestroy(c->gexec_u);
+    c->drop_graphs();
     for (auto &r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (void *p : c->allocs) hipFree(p);
     hipFree(c->ttab);
@@ -847,8 +855,10 @@ int shapemol_score(shapemol_ctx *c, const float *d_pos, const int64_t *d_v, cons
     if (ensure_workspace(c, N, B)) return 1;
     hipStream_t s = (hipStream_t)stream;
     c->lastN = N; c->lastB = B;
+    HIPCHK(hipMemsetAsync(c->status, 0, 8 * sizeof(int), s));
     if (DISPATCH_H(c, run_prep<128>(c, s, d_batch, N, B, d_shape), run_prep<32>(c, s, d_batch, N, B, d_shape))) return 1;
-    LAUNCH("prep", hipLaunchKernelGGL(t_convert_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d_t, (int)B, c->t_mol));
+    LAUNCH("prep", hipLaunchKernelGGL(t_convert_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d_t, (int)B, c->cfg.num_timesteps, c->t_mol, c->status));
+    LAUNCH("prep", hipLaunchKernelGGL(v_check_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_v, (int)N, c->cfg.num_classes, c->status));
     return DISPATCH_H(c, run_score<128>(c, s, d_pos, d_v, N, B, false, 0, out_pos, out_h, out_v),
                       run_score<32>(c, s, d_pos, d_v, N, B, false, 0, out_pos, out_h, out_v));
 }
@@ -865,19 +875,27 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
     hipStream_t s = (hipStream_t)stream;
     c->lastN = N; c->lastB = B;
     const int t_first = c->cfg.num_timesteps - 1;
+    HIPCHK(hipMemsetAsync(c->status, 0, 8 * sizeof(int), s));
     if (DISPATCH_H(c, run_prep<128>(c, s, d_batch, N, B, d_shape), run_prep<32>(c, s, d_batch, N, B, d_shape))) return 1;
+    LAUNCH("prep", hipLaunchKernelGGL(v_check_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_init_v, (int)N, c->cfg.num_classes, c->status));
+    {
+        ChainParams cp{};
+        cp.seed = seed; cp.eps = d_eps; cp.u = d_u;
+        if (traj) { cp.tr_pos = traj->pos_traj; cp.tr_v = traj->v_traj; cp.tr_v0 = traj->v0_traj; cp.tr_vt = traj->vt_traj;
+                    cp.tr_pos_cond = traj->pos_cond_traj; cp.tr_v_cond = traj->v_cond_traj; }
+        LAUNCH("prep", hipLaunchKernelGGL(set_chain_params_kernel, dim3(1), dim3(1), 0, s, c->chain_params, cp));
+    }
     HIPCHK(hipMemcpyAsync(c->x_state, d_init_pos, N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(c->v_state, d_init_v, N * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemsetAsync(c->steps, 0, 4 * sizeof(int), s));
     auto one_step = [&]() -> int {
         if (DISPATCH_H(c, run_score<128>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v),
                        run_score<32>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v))) return 1;
-        return DISPATCH_H(c, run_ddpm<128>(c, s, N, d_eps, d_u, seed, traj), run_ddpm<32>(c, s, N, d_eps, d_u, seed, traj));
+        return DISPATCH_H(c, run_ddpm<128>(c, s, N), run_ddpm<32>(c, s, N));
     };
     if (use_graph && !c->prof_on) {
         shapemol_ctx::GraphKey key{};
-        key.N = N; key.B = B; key.eps = d_eps; key.u = d_u; key.seed = seed; key.steps = 0;
-        if (traj) { key.tp[0] = traj->pos_traj; key.tp[1] = traj->v_traj; key.tp[2] = traj->v0_traj; key.tp[3] = traj->vt_traj; key.tp[4] = traj->pos_cond_traj; key.tp[5] = traj->v_cond_traj; }
+        key.N = N; key.B = B;
         // two executables: one reverse step, and kGraphUnroll steps back to back (the gap between two graph launches,
         // ~5 us, is then paid once per kGraphUnroll steps); every step reads its index from the device-side counter
         auto capture = [&](int n_steps, hipGraphExec_t *exec) -> int {
@@ -894,8 +912,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
             return 0;
         };
         if (!c->gexec || !(key == c->gkey)) {
-            if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-            if (c->gexec_u) { hipGraphExecDestroy(c->gexec_u); c->gexec_u = nullptr; }
+            c->drop_graphs();
             if (capture(1, &c->gexec)) return 1;
             c->gkey = key;
         }
@@ -934,8 +951,8 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     else if (k == "kstamp_sel") c->kstamp_sel = (int)value;
     else if (k == "edge_waves") { if (value < 0 || value > 12) return fail("edge_waves must be 0 (automatic) .. 12"); c->edge_threads = (int)value * 64; }   // 0 = automatic
     else return fail("unknown option " + k);
-    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-    if (c->gexec_u) { hipGraphExecDestroy(c->gexec_u); c->gexec_u = nullptr; }
+    hipSetDevice(c->device);
+    c->drop_graphs();
     return 0;
 }
 
@@ -957,13 +974,27 @@ int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t
     else if (k == "o3") { src = c->o3; bytes = N * 48 * 4; }
     else if (k == "stamps") { src = c->stamps; bytes = 2048 * 8; }
     else if (k == "kstamps") { src = c->kstamps; bytes = (size_t)8 * 16 * 4096 * 8; }
-    else if (k == "vn_err") { src = c->bn_acc + (size_t)g.num_layers * kBnReplicas * 2 * g.n_heads + g.num_layers; bytes = 4; }
+    else if (k == "vn_err") { src = c->status + ST_VN_BARRIER; bytes = 4; }
     else if (k == "bnstat") { src = c->bn_acc; bytes = (size_t)g.num_layers * kBnReplicas * 2 * g.n_heads * 8; }
     else { fail("shapemol_debug_read: unknown buffer " + k); return -1; }
     if (!src || bytes > max_bytes) { fail("shapemol_debug_read: buffer unavailable or destination too small"); return -1; }
     if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("shapemol_debug_read: copy failed"); return -1; }
     return (int64_t)bytes;
+}
+
+int shapemol_status(shapemol_ctx *c, int32_t *flags_out) {
+    if (!c) return fail("shapemol_status: null ctx");
+    int32_t f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (c->status) HIPCHK(hipMemcpy(f, c->status, sizeof(f), hipMemcpyDeviceToHost));
+    if (flags_out) std::memcpy(flags_out, f, sizeof(f));
+    if (f[ST_BATCH]) return fail("batch vector is not sorted ascending or names a molecule >= n_mols; results are invalid");
+    if (f[ST_ATOM_TYPE]) return fail("an atom type is outside [0, num_classes); results are invalid");
+    if (f[ST_TIME]) return fail("a time step is outside [0, num_timesteps); results are invalid");
+    if (f[ST_VN_BARRIER]) return fail("grid barrier of the fused coordinate update timed out (workgroups not co-resident); results are invalid");
+    return 0;
 }
 
 int shapemol_profile_begin(shapemol_ctx *c) {

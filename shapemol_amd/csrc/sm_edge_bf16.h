@@ -294,6 +294,10 @@ struct EdgeFusedArgs {
     } vn;
 };
 constexpr int kVnReplicas = 16;
+// doubles of reduction scratch behind the LDS images of the h2x kernel (host and device use the same formula)
+__host__ __device__ constexpr int vn_red_doubles(int nwave, int hd) {
+    return nwave * 64 > (2 + 2 * kVnReplicas) * hd ? nwave * 64 : (2 + 2 * kVnReplicas) * hd;
+}
 
 // ONE = true: the launch gives every wave at most one job (jobs <= workgroups x waves; the common case up to ~6k atoms):
 // the job loops become straight-line code and no next job's rows are kept in flight (fewer live registers).
@@ -441,8 +445,9 @@ edge_fused_kernel(EdgeFusedArgs a) {
     const float *imv = lds + V_BASE;
     constexpr int HD = H / 8;                                     // heads = VN channels
     // fused coordinate update (h2x): lane = (atom of the job, channel)
-    double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);   // [nwave][32][2] behind the images
-    float *vn_o = reinterpret_cast<float *>(vn_red + nwave * 64) + wave * (APJ * 48);   // this wave's attention rows [APJ][16][3]
+    double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);   // [nwave][32][2] behind the images; the grid-barrier
+                                                                              // epilogue stages [2 + 2 * kVnReplicas][HD] doubles there
+    float *vn_o = reinterpret_cast<float *>(vn_red + vn_red_doubles(nwave, HD)) + wave * (APJ * 48);   // this wave's attention rows [APJ][16][3]
     const bool one_job = njobs <= jstride;                                     // every wave has at most one job
     first = true;
     while (have) {

@@ -8,20 +8,35 @@
 // batch (N,) i64 sorted -> mol_of (N,) i32 and mol_off (B+1,) i32
 // (reference: batch_ligand = repeat_interleave(arange(B), counts), scripts/sample_diffusion.py:72)
 // ---------------------------------------------------------------------------------------------
-__global__ void mol_index_kernel(const int64_t *batch, int n, int n_mols, int *mol_of, int *mol_off) {
+// status flags of a context (device int[8], sticky until the next _score/_sample; read by shapemol_status)
+enum StatusFlag { ST_VN_BARRIER = 0, ST_BATCH = 1, ST_ATOM_TYPE = 2, ST_TIME = 3 };
+
+__global__ void mol_index_kernel(const int64_t *batch, int n, int n_mols, int *mol_of, int *mol_off, int *status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int b = (int)batch[i];
+    const int64_t braw = batch[i], praw = i == 0 ? -1 : batch[i - 1];
+    // a batch vector that is unsorted or names a molecule >= n_mols would corrupt the kNN ranges: flag it and clamp
+    if (braw < 0 || braw >= n_mols || braw < praw) status[ST_BATCH] = 1;
+    const int b = (int)min(max(braw, (int64_t)0), (int64_t)n_mols - 1);
+    const int prev = (int)min(max(praw, (int64_t)-1), (int64_t)n_mols - 1);
     mol_of[i] = b;
-    const int prev = i == 0 ? -1 : (int)batch[i - 1];
     for (int m = prev + 1; m <= b; ++m) mol_off[m] = i;       // also covers empty molecules
     if (i == n - 1)
         for (int m = b + 1; m <= n_mols; ++m) mol_off[m] = n;
 }
 
-__global__ void t_convert_kernel(const int64_t *t, int n_mols, int *t_mol) {
+__global__ void t_convert_kernel(const int64_t *t, int n_mols, int n_timesteps, int *t_mol, int *status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_mols) t_mol[i] = (int)t[i];
+    if (i >= n_mols) return;
+    const int64_t tr = t[i];
+    if (tr < 0 || tr >= n_timesteps) status[ST_TIME] = 1;
+    t_mol[i] = (int)min(max(tr, (int64_t)0), (int64_t)n_timesteps - 1);
+}
+
+// atom types must index the embedding table: flag and leave (the embedding stage clamps its own read)
+__global__ void v_check_kernel(const int64_t *v, int n, int n_classes, int *status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (v[i] < 0 || v[i] >= n_classes)) status[ST_ATOM_TYPE] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,12 +179,12 @@ __global__ void atom_embed_kernel(AtomEmbArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int step = a.step_ptr ? *a.step_ptr : 0;
     if (idx == 0 && a.step_ptr) *a.step_cur = step;
-    if (idx < a.bn_acc_len) a.bn_acc[idx] = 0.0;
+    for (int i = idx; i < a.bn_acc_len; i += gridDim.x * blockDim.x) a.bn_acc[i] = 0.0;
     if (idx >= a.n_atoms * a.H) return;
     const int i = idx / a.H, f = idx % a.H, ld = a.C + a.D;
     const int t = a.step_ptr ? a.t_first - step : a.t_mol[a.mol_of[i]];
     const float *w = a.w + (size_t)f * ld;
-    float y = a.b[f] + w[(int)a.v[i]];
+    float y = a.b[f] + w[min(max((int)a.v[i], 0), a.C - 1)];
     const float *te = a.ttab + (size_t)t * a.D;
     for (int k = 0; k < a.D; ++k) y += w[a.C + k] * te[k];
     a.h[idx] = y;
@@ -390,6 +405,16 @@ __global__ void vn_apply_kernel(VnArgs a) {
 // log_softmax, index_to_log_onehot (:64-68), q_v_posterior (:377-385) with the uniform mixing
 // of q_v_pred / q_v_pred_one_timestep (:323-364), Gumbel-argmax sampling (:98-104).
 // ---------------------------------------------------------------------------------------------
+// Per-chain parameters that change from call to call (noise source, trajectory buffers).  They live in DEVICE memory,
+// written by set_chain_params_kernel before the first step, so that the captured step graph does not depend on them:
+// a new seed or new trajectory buffers replay the same executable.
+struct ChainParams {
+    unsigned long long seed;
+    const float *eps, *u;    // host-fed noise of ALL steps ([S][N][3], [S][N][C]) or nullptr
+    float *tr_pos; int64_t *tr_v; float *tr_v0; float *tr_vt; float *tr_pos_cond; float *tr_v_cond;  // trajectories or nullptr
+};
+__global__ void set_chain_params_kernel(ChainParams *dst, ChainParams v) { *dst = v; }
+
 struct DdpmArgs {
     const float *pred_pos;   // [N][3]
     const float *pred_v;     // [N][C]
@@ -398,17 +423,18 @@ struct DdpmArgs {
     const int *mol_of;
     int t_first;             // t = t_first - step for every molecule
     const float *c0, *ct, *logvar, *log_a, *log_1ma, *log_abar, *log_1mabar;   // [T] tables
-    const float *eps, *u;    // host-fed noise of ALL steps ([S][N][3], [S][N][C]) or nullptr
+    const ChainParams *cp;   // noise source and trajectory buffers of this chain (device memory)
     const int *step_cur;     // this step's index (written by time_embed_kernel) or nullptr (= 0)
     int *step_ptr;           // device step counter, advanced here for the NEXT step (nobody reads it in this kernel)
-    uint64_t seed;
     float *x_next;           // [N][3]
     int64_t *v_next;         // [N]
-    float *tr_pos; int64_t *tr_v; float *tr_v0; float *tr_vt; float *tr_pos_cond; float *tr_v_cond;  // trajectories or nullptr
     int n_atoms, C;
 };
 template <int MAXC>
-__global__ void ddpm_step_kernel(DdpmArgs a) {
+__global__ void ddpm_step_kernel(DdpmArgs aa) {
+    struct : DdpmArgs, ChainParams {} a;
+    static_cast<DdpmArgs &>(a) = aa;
+    static_cast<ChainParams &>(a) = *aa.cp;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int step = a.step_cur ? *a.step_cur : 0;
     if (i < a.n_atoms) {
@@ -491,7 +517,10 @@ __global__ void ddpm_step_kernel(DdpmArgs a) {
 
 // Same step with 16 lanes per atom (one class per lane, C <= 16): the per-class transcendental chains
 // run in parallel and the reductions are DPP row operations.
-__global__ void __launch_bounds__(256) ddpm_step16_kernel(DdpmArgs a) {
+__global__ void __launch_bounds__(256) ddpm_step16_kernel(DdpmArgs aa) {
+    struct : DdpmArgs, ChainParams {} a;
+    static_cast<DdpmArgs &>(a) = aa;
+    static_cast<ChainParams &>(a) = *aa.cp;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i_raw = gid >> 4, c = gid & 15;
     const int step = a.step_cur ? *a.step_cur : 0;

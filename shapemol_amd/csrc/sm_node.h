@@ -796,7 +796,7 @@ node_prologue6_kernel(NodePrologueArgs a) {
         const int at = min(at_raw, a.n_atoms - 1);
         const int t = a.step_ptr ? a.t_first - step : a.t_mol[a.mol_of[at]];
         const float *te = a.ttab + (size_t)t * a.D;
-        const int vi = (int)a.v[at];
+        const int vi = min(max((int)a.v[at], 0), a.C - 1);       // out-of-range types are flagged by v_check_kernel
         const int fa = 32 * sb + 4 * (sl >> 4);
         float vv[8];
 #pragma unroll

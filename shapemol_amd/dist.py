@@ -20,29 +20,32 @@ def shard_batches(num_batches, rank, world_size):
 def gather_molecules(pos, v, counts, group=None):
     """All-gather the final molecules of every rank.
 
-    pos (N_r,3) f32, v (N_r,) i64, counts (B_r,) i64 atoms per molecule on this rank.
+    pos (N_r,3) f32, v (N_r,) i64, counts (B_r,) i64 atoms per molecule on this rank (a rank may own nothing).
     Returns (pos_all, v_all, counts_all) concatenated in rank order on every rank.
-    Ragged sizes are handled by padding to the largest rank (one all_gather of the sizes first)."""
+    Two collectives: one all-gather of the (N_r, B_r) sizes, then ONE padded ``all_gather_into_tensor`` of a packed
+    int32 buffer per rank: [pos bits (3 max_n) | atom types (max_n) | counts (max_b)] -- atom types (< num_classes)
+    and atom counts fit 32 bits, coordinates travel as their bit patterns."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return pos, v, counts
     ws = dist.get_world_size(group)
     dev = pos.device
-    sizes = torch.tensor([pos.shape[0], counts.shape[0]], dtype=torch.int64, device=dev)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(ws)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    max_n = int(max(s[0] for s in all_sizes))
-    max_b = int(max(s[1] for s in all_sizes))
-    # one payload per rank: positions, types and counts packed into a single int64/float32 pair
-    pad_pos = torch.zeros((max_n, 3), dtype=pos.dtype, device=dev); pad_pos[:pos.shape[0]] = pos
-    pad_iv = torch.zeros((max_n + max_b,), dtype=torch.int64, device=dev)
-    pad_iv[:v.shape[0]] = v
-    pad_iv[max_n:max_n + counts.shape[0]] = counts
-    g_pos = [torch.empty_like(pad_pos) for _ in range(ws)]
-    g_iv = [torch.empty_like(pad_iv) for _ in range(ws)]
-    dist.all_gather(g_pos, pad_pos, group=group)
-    dist.all_gather(g_iv, pad_iv, group=group)
+    n_r, b_r = int(pos.shape[0]), int(counts.shape[0])
+    sizes = torch.tensor([n_r, b_r], dtype=torch.int64, device=dev)
+    all_sizes = torch.empty((ws * 2,), dtype=torch.int64, device=dev)      # flat outputs: gloo and RCCL both accept them
+    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+    all_sizes = all_sizes.view(ws, 2).cpu()
+    max_n, max_b = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+    payload = torch.zeros((4 * max_n + max_b,), dtype=torch.int32, device=dev)
+    payload[:3 * n_r] = pos.to(torch.float32).contiguous().view(torch.int32).reshape(-1)
+    payload[3 * max_n:3 * max_n + n_r] = v.to(torch.int32)
+    payload[4 * max_n:4 * max_n + b_r] = counts.to(torch.int32)
+    gathered = torch.empty((ws * payload.numel(),), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(gathered, payload, group=group)
+    gathered = gathered.view(ws, payload.numel())
     out_p, out_v, out_c = [], [], []
     for r in range(ws):
-        n_r, b_r = int(all_sizes[r][0]), int(all_sizes[r][1])
-        out_p.append(g_pos[r][:n_r]); out_v.append(g_iv[r][:n_r]); out_c.append(g_iv[r][max_n:max_n + b_r])
+        nr, br = int(all_sizes[r, 0]), int(all_sizes[r, 1])
+        out_p.append(gathered[r, :3 * nr].view(torch.float32).reshape(nr, 3))
+        out_v.append(gathered[r, 3 * max_n:3 * max_n + nr].to(torch.int64))
+        out_c.append(gathered[r, 4 * max_n:4 * max_n + br].to(torch.int64))
     return torch.cat(out_p), torch.cat(out_v), torch.cat(out_c)

@@ -183,6 +183,7 @@ class ScorePosNet3D(nn.Module):
                                             _ptr(out_pos), _ptr(out_h), _ptr(out_v),
                                             _stream_ptr(torch.cuda.current_stream(dev)))
         _lib.check(rc, "shapemol_score")
+        self._pending_check = True      # device-side input flags are read at the next check_status()
         return {"pred_ligand_pos": out_pos, "pred_ligand_h": out_h, "pred_ligand_v": out_v}
 
     # ------------------------------------------------------------------ sampling
@@ -247,6 +248,8 @@ class ScorePosNet3D(nn.Module):
                                      1 if use_graph else 0, _stream_ptr(side))
             cur.wait_stream(side)
         _lib.check(rc, "shapemol_sample")
+        cur.synchronize()               # the reference returns finished results; also the point where input flags are read
+        self.check_status()
         for t_ in (pos, v, batch, shape, eps, u, out_pos, out_v, *bufs.values()):
             if t_ is not None:
                 t_.record_stream(side)
@@ -269,6 +272,13 @@ class ScorePosNet3D(nn.Module):
         else:
             res.update(pos_traj=[], v_traj=[], v0_traj=[], vt_traj=[], pos_cond_traj=[], v_cond_traj=[])
         return res
+
+    def check_status(self):
+        """Synchronise and raise if the last forward / sample_diffusion saw an invalid input (batch vector not sorted
+        or >= the number of shapes, atom type or time step out of range).  forward() stays asynchronous, so its flags
+        are read here or at the next sample_diffusion; the reference raises from torch's indexing ops instead."""
+        if self._ctx is not None:
+            _lib.check(_lib.load().shapemol_status(self._ctx, None), "input check")
 
     def _to_host(self, t, cache_key=None):
         """Device tensor -> host tensor with one pinned-memory DMA (falls back to a pageable copy).  With a cache key the

@@ -59,12 +59,10 @@ class ChainRunner:
         _lib.check(rc, "shapemol_sample")
 
     def synchronize(self):
+        """Wait for the chain and raise if the library flagged an invalid input (unsorted batch vector, atom type or
+        time step out of range) or a timed-out grid barrier (option vn_fuse = 1)."""
         self.stream.synchronize()
-        # the h2x kernel carries a grid barrier (coordinate update fused behind the attention); it reports a
-        # timed-out barrier (workgroups not co-resident, e.g. a shared GPU) instead of hanging
-        if int(self.model.debug_read("vn_err", (1,), np.int32)[0]) != 0:
-            raise _lib.ShapeMolLibraryError("grid barrier of the fused coordinate update timed out; "
-                                            "results are invalid (set_option('vn_fuse', 0) to use separate launches)")
+        _lib.check(_lib.load().shapemol_status(self.ctx, None), "chain")
 
     def profile(self, num_steps, seed=0):
         """Per-kernel-class launch time (HIP events on the launch stream, eager launches).

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Round-2 golden fixtures at the BASELINE.json configuration sizes, from the reference itself.
+
+Same harness as make_golden.py (the reference's own ``models`` package is imported in the build
+container and filled with the hash weights of ``shapemol_amd.synth``); kept in a second script
+because these take tens of CPU-minutes while make_golden.py's set regenerates in a few.
+
+    python tests/golden/make_golden_r2.py b256      # configs[1]: B=256 x 1000 steps   (~30 min)
+    python tests/golden/make_golden_r2.py b1024     # configs[2]: B=1024 x 50 steps    (~6 min)
+    python tests/golden/make_golden_r2.py k32       # configs[4]: <=80 atoms, k=32, L=8, B=64
+    python tests/golden/make_golden_r2.py all
+
+Noise is the hash noise of synth.step_noise (a pure function of (seed, step)), so the fixtures
+hold only the states: end pos / v, snapshots, and the first steps (so that the CPU suite can
+check the oracle against a few steps without a half-hour run).
+Reference entry points: /root/reference/models/molopt_score_model.py:286-320 (forward),
+:533-697 (sample_diffusion).
+"""
+import contextlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as G  # noqa: E402
+from shapemol_amd import synth  # noqa: E402
+
+t_ = G.t_
+
+
+def chain(model, tag, B, S, seed, every, head, atoms_range=None, max_atoms=None):
+    bb = synth.synthetic_batch(B, seed=seed, atoms_range=atoms_range, max_atoms=max_atoms)
+    n = len(bb["batch"])
+    eps, u = zip(*[synth.step_noise(n, 15, s, seed=seed) for s in range(S)])
+    t0 = time.time()
+    with G.fed_noise(list(eps), list(u)), contextlib.redirect_stdout(open(os.devnull, "w")):
+        r = model.sample_diffusion(t_(bb["init_pos"]), t_(bb["init_v"]), t_(bb["batch"]),
+                                   t_(bb["shape"]).view(B, -1), num_steps=S, center_pos_mode="none")
+    pos_traj = torch.stack(r["pos_traj"]).numpy()
+    v_traj = torch.stack(r["v_traj"]).numpy()
+    logp = torch.stack(r["vt_traj"]).numpy()
+    top2 = np.sort(logp, -1)[..., -2:]
+    np.savez_compressed(
+        os.path.join(HERE, f"chain_{tag}_hash.npz"), B=B, S=S, seed=seed, every=every, head=head,
+        counts=bb["counts"], pos=r["pos"].numpy(), v=r["v"].numpy(),
+        pos_traj_sub=pos_traj[::every], v_traj_sub=v_traj[::every].astype(np.int8),
+        pos_traj_head=pos_traj[:head], v_traj_head=v_traj[:head].astype(np.int8),
+        pos0_first=r["pos_cond_traj"][0].numpy(), v0_first=r["v0_traj"][0].numpy(),
+        vt_last=r["vt_traj"][-1].numpy())
+    print(f"chain {tag}: N = {n}, {S} steps in {time.time() - t0:.0f} s", flush=True)
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+    if what in ("b256", "b1024", "all"):
+        model, _ = G.load_reference_model()
+        G.synthetic_load(model, seed=7)
+        if what in ("b1024", "all"):
+            chain(model, "b1024_s50", 1024, 50, 14, every=10, head=2, max_atoms=38)
+        if what in ("b256", "all"):
+            chain(model, "b256_s1000", 256, 1000, 13, every=50, head=4, max_atoms=38)
+    if what in ("k32", "all"):
+        # configs[4] analogue: 40-80 atom molecules, knn = 32, full depth
+        m2, _ = G.load_reference_model(dict(knn=32))
+        G.synthetic_load(m2, seed=9)
+        B = 64
+        bb = synth.synthetic_batch(B, seed=35, atoms_range=(40, 80))
+        tt = (synth.hash_u24(B, 78, 1) % 1000).astype(np.int64)
+        with torch.no_grad():
+            out = m2(t_(bb["init_pos"]), t_(bb["init_v"]), t_(bb["batch"]), t_(bb["shape"]), time_step=t_(tt))
+        np.savez_compressed(os.path.join(HERE, "forward_k32_b64.npz"), t=tt, counts=bb["counts"],
+                            **{k: o.numpy() for k, o in out.items()})
+        print("forward k32_b64: N =", len(bb["batch"]), flush=True)
+        chain(m2, "k32_b64_s20", B, 20, 36, every=5, head=2, atoms_range=(40, 80))
+
+
+if __name__ == "__main__":
+    main()

@@ -27,40 +27,52 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _rank_batch(rank, empty_rank):
+    """What rank `rank` "sampled": differently sized batches; `empty_rank` owns nothing (more ranks than batches)."""
+    if rank == empty_rank:
+        return np.zeros((0, 3), np.float32), np.zeros((0,), np.int64), np.zeros((0,), np.int64)
+    bb = synth.synthetic_batch(3 + rank, seed=100 + rank)
+    return (bb["init_pos"] + rank).astype(np.float32), bb["init_v"], bb["counts"]
+
+
+def _worker(rank, world, port, q, empty_rank):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        # each rank "samples" a different, differently sized batch (rank 1 owns one molecule more)
-        bb = synth.synthetic_batch(3 + rank, seed=100 + rank)
-        pos = torch.from_numpy(bb["init_pos"]) + rank
-        v = torch.from_numpy(bb["init_v"])
-        counts = torch.from_numpy(bb["counts"])
+        pos, v, counts = (torch.from_numpy(a) for a in _rank_batch(rank, empty_rank))
         p, vv, c = gather_molecules(pos, v, counts)
         q.put((rank, p.numpy(), vv.numpy(), c.numpy()))
     finally:
         dist.destroy_process_group()
 
 
-def test_gather_molecules_gloo_world2():
+def _run_gather(world, empty_rank=-1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, empty_rank)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    exp_p, exp_v, exp_c = [], [], []
-    for r in range(2):
-        bb = synth.synthetic_batch(3 + r, seed=100 + r)
-        exp_p.append(bb["init_pos"] + r); exp_v.append(bb["init_v"]); exp_c.append(bb["counts"])
-    exp_p, exp_v, exp_c = np.concatenate(exp_p), np.concatenate(exp_v), np.concatenate(exp_c)
+    parts = [_rank_batch(r, empty_rank) for r in range(world)]
+    exp_p, exp_v, exp_c = (np.concatenate([pt[i] for pt in parts]) for i in range(3))
+    assert sorted(r for r, *_ in got) == list(range(world))
     for rank, p, v, c in got:
-        assert np.array_equal(p, exp_p.astype(np.float32)) and np.array_equal(v, exp_v) and np.array_equal(c, exp_c)
+        assert p.dtype == np.float32 and v.dtype == np.int64 and c.dtype == np.int64
+        assert np.array_equal(p, exp_p) and np.array_equal(v, exp_v) and np.array_equal(c, exp_c)
     assert exp_c.sum() == len(exp_v)
+
+
+def test_gather_molecules_gloo_world2():
+    _run_gather(2)
+
+
+def test_gather_molecules_gloo_world3_with_empty_rank():
+    """Three ranks, the middle one owns no batch at all (more ranks than batches): ragged padding down to zero rows."""
+    _run_gather(3, empty_rank=1)
 
 
 def test_gather_is_identity_without_process_group():

@@ -85,7 +85,7 @@ def test_library_exports_every_header_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.shapemol_abi_version() == 1
+    assert lib.shapemol_abi_version() == _lib.ABI_VERSION
 
 
 def test_header_is_plain_c():
