@@ -11,9 +11,11 @@ Inputs are resident in HBM before the timed region; noise is generated on the de
 inside it; per-step trajectories are written to HBM inside it (their D2H copy is reported
 separately as `traj_d2h_ms`, never part of `value`).
 
-Also on the JSON line: `roofline` of the dominant kernel (per-launch time from HIP events on the
-launch stream, measured live in a short eager pass after the timed region) and `cpu_baseline`
-(the CPU oracle timed on this host's cores on a bounded sample; rank 0, N = 1 only).
+Also on the JSON line: `roofline` of the dominant kernel -- per-launch time from the begin/end
+timestamps of the kernel dispatches themselves (hipExtLaunchKernelGGL start/stop events on the launch
+stream, the quantity rocprofv3's kernel trace reports), measured live in a short pass after the timed
+region -- and `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample; rank 0,
+N = 1 only).
 """
 import argparse
 import json
@@ -55,8 +57,8 @@ def reference_flops_per_atom_step(k, L=8):
 def cpu_baseline(cfg, batch, n_steps):
     """The CPU oracle on the same workload, timed on this host (bounded sample)."""
     from oracle import shapemol_oracle as O
-    # the box's CPU share is smaller than os.cpu_count(): oversubscribing OpenMP stalls the run
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), 16)))
+    # the box's CPU share (16 cores per GPU) is smaller than os.cpu_count(): oversubscribing OpenMP stalls the run
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)), 16)))
     sd = O.state_dict_from_numpy(synth.synthetic_state_dict(cfg, seed=7))
     dm = O.Dims(cfg)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
@@ -81,7 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="molecules per GPU (BASELINE config 2: 256)")
     ap.add_argument("--profile-steps", type=int, default=10)
-    ap.add_argument("--cpu-steps", type=int, default=6, help="reverse steps of the CPU oracle to time (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=20, help="reverse steps of the CPU oracle to time (0 = skip)")
     ap.add_argument("--no-traj", action="store_true", help="do not keep per-step trajectories")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--concurrent", type=int, default=2,

@@ -118,7 +118,10 @@ int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, co
                                     int64_t *out_index, void *stream);
 
 /* ---- diagnostics (used by the parity tests and the bench; not needed by a caller) ---- */
-/* options: "stop_layer" (run only the first v layers of the next _score; -1 = all),
+/* options: "first_step" (the following _sample calls resume a chain at reverse step v, i.e. at t = T-1-v, from the
+ *                        state given as d_init_pos / d_init_v; noise and trajectory rows stay indexed from 0; default 0.
+ *                        Used by the windowed full-length parity test; the reference always starts at T-1),
+ *          "stop_layer" (run only the first v layers of the next _score; -1 = all),
  *          "edge_bf16"  (1 = fused key/value edge kernel with exactly split bf16 second Linears [default],
  *                        2 = the same arithmetic as separate key / value launches, 0 = fp32-MFMA edge kernels;
  *                        k > 16 always uses the fp32 kernels),
@@ -134,7 +137,8 @@ int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, co
 int shapemol_set_option(shapemol_ctx *ctx, const char *name, int64_t value);
 /* Copy an internal device buffer of the last _score to HOST memory (synchronises the device).
  * names: "nbr" (N,KP) i32, "ew" (N,KP) f32, "h" (N,H), "x" (N,3), "pre" (N,4H), "q" (N,H),
- *        "att" (N,H), "o3" (N,48), "bnstat" (L,16,2,heads) f64, "dims" (8,) i64.
+ *        "att" (N,H), "o3" (N,48), "bnstat" (L,16,2,heads) f64, "dims" (8,) i64,
+ *        "captures" (1,) i64 hipGraph captures of this context so far.
  * Returns the number of bytes written, or -1. */
 int64_t shapemol_debug_read(shapemol_ctx *ctx, const char *name, void *host_dst, size_t max_bytes);
 /* Per-kernel launch-time accounting with HIP events on the launch stream (bench only).

@@ -8,6 +8,7 @@
 #include "sm_edge_bf16.h"
 #include "sm_node.h"
 #include "sm_misc.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -377,11 +378,14 @@ struct shapemol_ctx {
     // options
     int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 1, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
     int num_cu = 256;
+    int first_step = 0;         // option "first_step": the next chains start at reverse step first_step (t = T-1-first_step)
     // profiling
     bool prof_on = false;
     std::vector<ProfRec> prof;
+    hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;     // event pair of the launch being issued
     // graph cache
     hipGraphExec_t gexec = nullptr, gexec_u = nullptr;     // one step / kGraphUnroll steps
+    int64_t n_captures = 0;                                // graph captures so far (debug_read "captures")
     // the captured step depends on the batch geometry only: seed, noise and trajectory pointers live in chain_params
     struct GraphKey { int64_t N = 0, B = 0; bool operator==(const GraphKey &o) const { return N == o.N && B == o.B; } } gkey{};
     void drop_graphs() {      // a replay may still be in flight: drain the device before destroying the executables
@@ -395,14 +399,23 @@ struct shapemol_ctx {
 
 namespace {
 
+// Profiling mode (shapemol_profile_begin): every kernel is launched with hipExtLaunchKernelGGL and a start/stop event
+// pair that takes the begin/end timestamps of the DISPATCH ITSELF (what rocprofv3's kernel trace reports), not of
+// marker packets around it.
+#define SMK(kern, grid, block, shm, stream, ...)                                                                    \
+    do {                                                                                                             \
+        if (c->prof_on) hipExtLaunchKernelGGL(kern, grid, block, shm, stream, c->cur_e0, c->cur_e1, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, shm, stream, __VA_ARGS__);                                        \
+    } while (0)
+
 template <typename F>
 int launch(shapemol_ctx *c, const char *name, hipStream_t s, F &&f) {
+    (void)s;
     if (c->prof_on) {
         ProfRec r{name, nullptr, nullptr};
         HIPCHK(hipEventCreate(&r.e0)); HIPCHK(hipEventCreate(&r.e1));
-        HIPCHK(hipEventRecord(r.e0, s));
+        c->cur_e0 = r.e0; c->cur_e1 = r.e1;
         f();
-        HIPCHK(hipEventRecord(r.e1, s));
         c->prof.push_back(r);
     } else {
         f();
@@ -489,9 +502,9 @@ int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {
                               : std::max(1, std::min(c->num_cu, njobs));
     const size_t shm = EdgeBlob<H, H2X>::TOTAL * sizeof(float);
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
-    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
-    else if (KP == 16) LAUNCH(nm, hipLaunchKernelGGL((edge_attention_t1_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
-    else LAUNCH(nm, hipLaunchKernelGGL((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    if (KP == 8) LAUNCH(nm, SMK((edge_attention_t1_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else if (KP == 16) LAUNCH(nm, SMK((edge_attention_t1_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else LAUNCH(nm, SMK((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     return 0;
 }
 
@@ -501,8 +514,8 @@ int launch_phase(shapemol_ctx *c, hipStream_t s, const char *nm, const EdgePhase
     const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
     const size_t shm = EdgePhaseImage<H, (MODE == PH_VH ? 1 : H / 16)>::TOTAL * sizeof(float);
-    if (KP == 8) LAUNCH(nm, hipLaunchKernelGGL((edge_phase_kernel<H, 8, MODE>), dim3(grid), dim3(waves * 64), shm, s, a));
-    else LAUNCH(nm, hipLaunchKernelGGL((edge_phase_kernel<H, 16, MODE>), dim3(grid), dim3(waves * 64), shm, s, a));
+    if (KP == 8) LAUNCH(nm, SMK((edge_phase_kernel<H, 8, MODE>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else LAUNCH(nm, SMK((edge_phase_kernel<H, 16, MODE>), dim3(grid), dim3(waves * 64), shm, s, a));
     return 0;
 }
 
@@ -516,11 +529,11 @@ int launch_fused(shapemol_ctx *c, hipStream_t s, const EdgeFusedArgs &a) {
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
     const bool one = njobs <= grid * waves;      // every wave has at most one job: straight-line instantiation
     if (KP == 8) {
-        if (one) LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 8, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
-        else LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+        if (one) LAUNCH(nm, SMK((edge_fused_kernel<H, 8, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
+        else LAUNCH(nm, SMK((edge_fused_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
     } else {
-        if (one) LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 16, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
-        else LAUNCH(nm, hipLaunchKernelGGL((edge_fused_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+        if (one) LAUNCH(nm, SMK((edge_fused_kernel<H, 16, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
+        else LAUNCH(nm, SMK((edge_fused_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
     }
     return 0;
 }
@@ -533,7 +546,7 @@ int launch_mlp2(shapemol_ctx *c, hipStream_t s, const char *name, const DevMlpIm
     a.w2img = c->P(m.w2img); a.b2 = c->P(m.b2); a.resid = resid; a.out = out; a.ld_out = ld_out; a.n_store = n_store;
     a.mode = mode; a.nt2 = m.nt2; a.n_atoms = n_atoms;
     const int n_ct = (n_atoms + 15) / 16, teams = NodeMlpLds<H>::TEAMS;
-    LAUNCH(name, hipLaunchKernelGGL((node_mlp2_kernel<H, KT>), dim3((n_ct + teams - 1) / teams), dim3(kNodeThreads), 0, s, a));
+    LAUNCH(name, SMK((node_mlp2_kernel<H, KT>), dim3((n_ct + teams - 1) / teams), dim3(kNodeThreads), 0, s, a));
     return 0;
 }
 
@@ -548,9 +561,9 @@ int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float 
     NodeLinArgs a{in, c->lin_bf16 ? wimg6 : wimg, add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps};
     if (c->lin_bf16) {
         const size_t shm = (size_t)std::min(tpg, kLin6Chunk) * 3 * H * 32;
-        LAUNCH(name, hipLaunchKernelGGL(node_linear6_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a));
+        LAUNCH(name, SMK(node_linear6_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a));
     } else {
-        LAUNCH(name, hipLaunchKernelGGL(node_linear_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), 0, s, a));
+        LAUNCH(name, SMK(node_linear_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), 0, s, a));
     }
     return 0;
 }
@@ -568,28 +581,28 @@ template <int H>
 int run_prep(shapemol_ctx *c, hipStream_t s, const int64_t *d_batch, int64_t N, int64_t B, const float *d_shape) {
     const shapemol_config &g = c->cfg;
     const int L = g.num_layers, hd = g.n_heads, SL = g.shape_latent_dim, S = g.shape_dim;
-    LAUNCH("prep", hipLaunchKernelGGL(mol_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_batch, (int)N, (int)B, c->mol_of, c->mol_off, c->status));
+    LAUNCH("prep", SMK(mol_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_batch, (int)N, (int)B, c->mol_of, c->mol_off, c->status));
     ShapeInvArgs si{d_shape, c->P(c->dm.inv.w1), c->P(c->dm.inv.b1), c->P(c->dm.inv.g), c->P(c->dm.inv.be),
                     c->P(c->dm.inv.w2), c->P(c->dm.inv.b2), c->inv, S, SL};
-    LAUNCH("prep", hipLaunchKernelGGL(shape_invariant_kernel, dim3(B), dim3(64), 0, s, si));
+    LAUNCH("prep", SMK(shape_invariant_kernel, dim3(B), dim3(64), 0, s, si));
     {   // layer-0 x2h term: [B][4H]
         const DevLayer &D = c->dm.layer[0];
         ShapeTermArgs st{c->inv, c->P(D.sk_x2h), c->P(D.bk_x2h), c->P(D.sv_x2h), c->P(D.bv_x2h), c->add0, SL, H, SL, 4 * H};
-        LAUNCH("prep", hipLaunchKernelGGL(shape_term_kernel, dim3(B), dim3(256), 0, s, st));
+        LAUNCH("prep", SMK(shape_term_kernel, dim3(B), dim3(256), 0, s, st));
     }
     for (int l = 0; l < L; ++l) {
         const DevLayer &D = c->dm.layer[l];
         // paired terms [B][8H]: this layer's h2x | the next layer's x2h (both products of the same new h)
         float *addp = c->addp + (size_t)l * c->capB * 8 * H;
         ShapeTermArgs st2{c->inv, c->P(D.sk_h2x), c->P(D.bk_h2x), c->P(D.sv_h2x), c->P(D.bv_h2x), addp, SL, H, SL, 8 * H};
-        LAUNCH("prep", hipLaunchKernelGGL(shape_term_kernel, dim3(B), dim3(256), 0, s, st2));
+        LAUNCH("prep", SMK(shape_term_kernel, dim3(B), dim3(256), 0, s, st2));
         if (l + 1 < L) {
             const DevLayer &Dn = c->dm.layer[l + 1];
             ShapeTermArgs st{c->inv, c->P(Dn.sk_x2h), c->P(Dn.bk_x2h), c->P(Dn.sv_x2h), c->P(Dn.bv_x2h), addp + 4 * H, SL, H, SL, 8 * H};
-            LAUNCH("prep", hipLaunchKernelGGL(shape_term_kernel, dim3(B), dim3(256), 0, s, st));
+            LAUNCH("prep", SMK(shape_term_kernel, dim3(B), dim3(256), 0, s, st));
         }
         VnShapeArgs vs{d_shape, c->P(D.vn_f), c->P(D.vn_d), c->ps + (size_t)l * c->capB * 2 * hd * 3, S, hd};
-        LAUNCH("prep", hipLaunchKernelGGL(vn_shape_kernel, dim3(B), dim3(128), 0, s, vs));
+        LAUNCH("prep", SMK(vn_shape_kernel, dim3(B), dim3(128), 0, s, vs));
     }
     return 0;
 }
@@ -615,17 +628,17 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         pa.n_lin_tiles = nlay > 0 ? 4 * (H / 16) : 0; pa.ld_add = 4 * H; pa.ld_out = 4 * H;
         pa.n_atoms = n; pa.C = C; pa.D = D; pa.t_first = t_first; pa.bn_acc_len = ae.bn_acc_len;
         const int n_ct = (n + 15) / 16;
-        LAUNCH("node_prologue", hipLaunchKernelGGL(node_prologue6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
+        LAUNCH("node_prologue", SMK(node_prologue6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
                                                    2 * Chain6Lds<H>::FRAG * 16 + Chain6Lds<H>::PRE * 4, s, pa));
     } else {
-        LAUNCH("embed", hipLaunchKernelGGL(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
+        LAUNCH("embed", SMK(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
     }
-    LAUNCH("knn", hipLaunchKernelGGL(knn_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x_in, c->mol_of, c->mol_off, n, g.knn, KP, c->nbr));
+    LAUNCH("knn", SMK(knn_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x_in, c->mol_of, c->mol_off, n, g.knn, KP, c->nbr));
     EdgeWeightArgs ea{x_in, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
                       c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, n * KP, KP};
     {
         const int tiles = (n * KP + 15) / 16;
-        LAUNCH("edge_weight", hipLaunchKernelGGL(edge_weight_kernel<H>, dim3((tiles + 3) / 4), dim3(256), 0, s, ea));
+        LAUNCH("edge_weight", SMK(edge_weight_kernel<H>, dim3((tiles + 3) / 4), dim3(256), 0, s, ea));
     }
     const float *cur_x = x_in;
     float *cur_h = c->h_a;
@@ -670,8 +683,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             if (has_next) { na.f[1] = follow_of(c, c->dm.layer[l + 1].q_x2h, NODE_LN_RELU, c->q_x, H, H); na.n_follow = 2; }
             else if (out_v) { na.f[1] = follow_of(c, c->dm.vhead, NODE_SSP, out_v, C, C); na.n_follow = 2; v_done = true; }
             const int n_ct = (n + 15) / 16;
-            if (c->chain_bf16) LAUNCH("node_chain", hipLaunchKernelGGL(node_chain6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain6Lds<H>::BYTES, s, na));
-            else LAUNCH("node_chain", hipLaunchKernelGGL(node_chain_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), 0, s, na));
+            if (c->chain_bf16) LAUNCH("node_chain", SMK(node_chain6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain6Lds<H>::BYTES, s, na));
+            else LAUNCH("node_chain", SMK(node_chain_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), 0, s, na));
             cur_h = dst;
             // per-node halves of the edge MLPs' first Linear: h2x of this layer | x2h of the next one
             if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->P(Dl.lin6_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
@@ -704,8 +717,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                   c->P(Dl.wd_o), c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, x_next, n, hd};
         const int per_blk = 256 / hd;
         if (!vn_done) {
-            if (!stats_done) LAUNCH("vn_stats", hipLaunchKernelGGL(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(kVnThreads), 0, s, va));
-            LAUNCH("vn_apply", hipLaunchKernelGGL(vn_apply_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
+            if (!stats_done) LAUNCH("vn_stats", SMK(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(kVnThreads), 0, s, va));
+            LAUNCH("vn_apply", SMK(vn_apply_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
         }
         cur_x = x_next;
     }
@@ -728,9 +741,9 @@ int run_ddpm(shapemol_ctx *c, hipStream_t s, int64_t N) {
     a.cp = c->chain_params; a.step_cur = c->steps + 1; a.step_ptr = c->steps;
     a.x_next = c->x_state; a.v_next = c->v_state;
     a.n_atoms = (int)N; a.C = g.num_classes;
-    if (c->stamp_on) LAUNCH("stamp", hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(64), 0, s, c->stamps, c->steps + 1, 1024));
-    if (g.num_classes <= 16) LAUNCH("ddpm", hipLaunchKernelGGL(ddpm_step16_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, s, a));
-    else LAUNCH("ddpm", hipLaunchKernelGGL(ddpm_step_kernel<32>, dim3((N + 127) / 128), dim3(128), 0, s, a));
+    if (c->stamp_on) LAUNCH("stamp", SMK(clock_stamp_kernel, dim3(1), dim3(64), 0, s, c->stamps, c->steps + 1, 1024));
+    if (g.num_classes <= 16) LAUNCH("ddpm", SMK(ddpm_step16_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, s, a));
+    else LAUNCH("ddpm", SMK(ddpm_step_kernel<32>, dim3((N + 127) / 128), dim3(128), 0, s, a));
     return 0;
 }
 
@@ -857,8 +870,8 @@ int shapemol_score(shapemol_ctx *c, const float *d_pos, const int64_t *d_v, cons
     c->lastN = N; c->lastB = B;
     HIPCHK(hipMemsetAsync(c->status, 0, 8 * sizeof(int), s));
     if (DISPATCH_H(c, run_prep<128>(c, s, d_batch, N, B, d_shape), run_prep<32>(c, s, d_batch, N, B, d_shape))) return 1;
-    LAUNCH("prep", hipLaunchKernelGGL(t_convert_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d_t, (int)B, c->cfg.num_timesteps, c->t_mol, c->status));
-    LAUNCH("prep", hipLaunchKernelGGL(v_check_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_v, (int)N, c->cfg.num_classes, c->status));
+    LAUNCH("prep", SMK(t_convert_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d_t, (int)B, c->cfg.num_timesteps, c->t_mol, c->status));
+    LAUNCH("prep", SMK(v_check_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_v, (int)N, c->cfg.num_classes, c->status));
     return DISPATCH_H(c, run_score<128>(c, s, d_pos, d_v, N, B, false, 0, out_pos, out_h, out_v),
                       run_score<32>(c, s, d_pos, d_v, N, B, false, 0, out_pos, out_h, out_v));
 }
@@ -868,7 +881,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
                     uint64_t seed, const shapemol_traj *traj, float *out_pos, int64_t *out_v, int32_t use_graph, void *stream) {
     if (!c || !d_init_pos || !d_init_v || !d_batch || !d_shape || !out_pos || !out_v) return fail("shapemol_sample: null argument");
     if (N < 1 || B < 1 || N > (1 << 27)) return fail("shapemol_sample: n_atoms / n_mols out of range");
-    if (num_steps < 1 || num_steps > c->cfg.num_timesteps) return fail("shapemol_sample: num_steps out of range");
+    if (num_steps < 1 || c->first_step + num_steps > c->cfg.num_timesteps) return fail("shapemol_sample: num_steps out of range");
     if ((d_eps == nullptr) != (d_u == nullptr)) return fail("shapemol_sample: d_eps and d_u must be given together");
     HIPCHK(hipSetDevice(c->device));
     if (ensure_workspace(c, N, B)) return 1;
@@ -877,17 +890,16 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
     const int t_first = c->cfg.num_timesteps - 1;
     HIPCHK(hipMemsetAsync(c->status, 0, 8 * sizeof(int), s));
     if (DISPATCH_H(c, run_prep<128>(c, s, d_batch, N, B, d_shape), run_prep<32>(c, s, d_batch, N, B, d_shape))) return 1;
-    LAUNCH("prep", hipLaunchKernelGGL(v_check_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_init_v, (int)N, c->cfg.num_classes, c->status));
+    LAUNCH("prep", SMK(v_check_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_init_v, (int)N, c->cfg.num_classes, c->status));
     {
         ChainParams cp{};
-        cp.seed = seed; cp.eps = d_eps; cp.u = d_u;
+        cp.seed = seed; cp.eps = d_eps; cp.u = d_u; cp.step_base = c->first_step;
         if (traj) { cp.tr_pos = traj->pos_traj; cp.tr_v = traj->v_traj; cp.tr_v0 = traj->v0_traj; cp.tr_vt = traj->vt_traj;
                     cp.tr_pos_cond = traj->pos_cond_traj; cp.tr_v_cond = traj->v_cond_traj; }
-        LAUNCH("prep", hipLaunchKernelGGL(set_chain_params_kernel, dim3(1), dim3(1), 0, s, c->chain_params, cp));
+        LAUNCH("prep", SMK(set_chain_params_kernel, dim3(1), dim3(1), 0, s, c->chain_params, cp, c->steps));
     }
     HIPCHK(hipMemcpyAsync(c->x_state, d_init_pos, N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(c->v_state, d_init_v, N * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemsetAsync(c->steps, 0, 4 * sizeof(int), s));
     auto one_step = [&]() -> int {
         if (DISPATCH_H(c, run_score<128>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v),
                        run_score<32>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v))) return 1;
@@ -909,6 +921,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
             const hipError_t ie = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
             hipGraphDestroy(graph);
             if (ie != hipSuccess) { *exec = nullptr; return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+            ++c->n_captures;
             return 0;
         };
         if (!c->gexec || !(key == c->gkey)) {
@@ -941,6 +954,11 @@ int shapemol_log_sample_categorical(shapemol_ctx *c, const float *d_logits, cons
 int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail("shapemol_set_option: null argument");
     const std::string k(name);
+    if (k == "first_step") {      // does not touch the captured graph: the step counter lives in device memory
+        if (value < 0 || value >= c->cfg.num_timesteps) return fail("first_step must be in [0, num_timesteps)");
+        c->first_step = (int)value;
+        return 0;
+    }
     if (k == "stop_layer") c->stop_layer = (int)value;
     else if (k == "edge_bf16") c->edge_bf16 = (int)value;
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
@@ -964,6 +982,7 @@ int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t
     const void *src = nullptr; size_t bytes = 0;
     int64_t dims[8] = {N, c->lastB, c->KP, g.hidden_dim, g.n_heads, g.num_layers, c->capN, c->capB};
     if (k == "dims") { if (max_bytes < sizeof(dims)) return -1; std::memcpy(dst, dims, sizeof(dims)); return sizeof(dims); }
+    if (k == "captures") { if (max_bytes < 8) return -1; std::memcpy(dst, &c->n_captures, 8); return 8; }
     if (k == "nbr") { src = c->nbr; bytes = N * c->KP * 4; }
     else if (k == "ew") { src = c->ew; bytes = N * c->KP * 4; }
     else if (k == "h") { src = c->last_h; bytes = N * g.hidden_dim * 4; }

@@ -412,8 +412,10 @@ struct ChainParams {
     unsigned long long seed;
     const float *eps, *u;    // host-fed noise of ALL steps ([S][N][3], [S][N][C]) or nullptr
     float *tr_pos; int64_t *tr_v; float *tr_v0; float *tr_vt; float *tr_pos_cond; float *tr_v_cond;  // trajectories or nullptr
+    int step_base;           // index of the chain's first reverse step (0 unless a chain is resumed mid-way): noise and
+                             // trajectory rows are indexed by step - step_base
 };
-__global__ void set_chain_params_kernel(ChainParams *dst, ChainParams v) { *dst = v; }
+__global__ void set_chain_params_kernel(ChainParams *dst, ChainParams v, int *step_counter) { *dst = v; *step_counter = v.step_base; }
 
 struct DdpmArgs {
     const float *pred_pos;   // [N][3]
@@ -440,7 +442,7 @@ __global__ void ddpm_step_kernel(DdpmArgs aa) {
     if (i < a.n_atoms) {
         const int C = a.C;
         const int t = a.t_first - step;
-        const size_t so = (size_t)step * a.n_atoms + i;
+        const size_t so = (size_t)(step - a.step_base) * a.n_atoms + i;
         float e3[3], uu[MAXC];
         if (a.eps) {
 #pragma unroll
@@ -529,7 +531,7 @@ __global__ void __launch_bounds__(256) ddpm_step16_kernel(DdpmArgs aa) {
     const int C = a.C;
     const bool cls = c < C;
     const int t = a.t_first - step;
-    const size_t so = (size_t)step * a.n_atoms + i;
+    const size_t so = (size_t)(step - a.step_base) * a.n_atoms + i;
     float eps = 0.f, uu = 0.5f;
     if (a.eps) {
         if (c < 3) eps = a.eps[so * 3 + c];

@@ -192,13 +192,15 @@ class ScorePosNet3D(nn.Module):
                          threshold_args=None, num_steps=None, center_pos_mode=None, use_grad=False, grad_lr=1,
                          shape_AE=None, use_mesh_data=None, use_pointcloud_data=None, grad_step=500,
                          guide_stren=0, bounds=None, *, noise=None, seed=None, return_traj=True, use_graph=True,
-                         _reuse_host_buffers=False):
+                         first_step=0, _reuse_host_buffers=False):
         """Reverse diffusion chain; same arguments and result dict as the reference.
 
         Extensions (keyword-only): ``noise=(eps, u)`` feeds host-chosen draws, eps (S,N,3) and u (S,N,C)
         device tensors in the reference's per-step order; otherwise device Philox noise keyed by
         ``seed`` (default: drawn from torch's CPU generator, so ``torch.manual_seed`` governs it).
         ``return_traj=False`` skips the per-step trajectories (the lists come back empty).
+        ``first_step=s`` resumes a chain at reverse step s (t = T-1-s) from the given state and runs ``num_steps``
+        steps from there (the windowed full-length parity test; the reference always starts at T-1).
         """
         if use_mesh_data is not None or use_pointcloud_data is not None or use_grad:
             raise NotImplementedError("mesh / point-cloud / gradient shape guidance is outside the accelerated path")
@@ -243,9 +245,13 @@ class ScorePosNet3D(nn.Module):
             # hipGraph capture is not allowed on the legacy default stream: run the chain on a side stream
             side = self._side_stream(dev)
             side.wait_stream(cur)
+            if first_step:
+                _lib.check(lib.shapemol_set_option(ctx, b"first_step", int(first_step)), "shapemol_set_option")
             rc = lib.shapemol_sample(ctx, _ptr(pos), _ptr(v), _ptr(batch), n, b, _ptr(shape), int(num_steps),
                                      _ptr(eps), _ptr(u), C.c_uint64(seed), C.byref(tr), _ptr(out_pos), _ptr(out_v),
                                      1 if use_graph else 0, _stream_ptr(side))
+            if first_step:
+                lib.shapemol_set_option(ctx, b"first_step", 0)
             cur.wait_stream(side)
         _lib.check(rc, "shapemol_sample")
         cur.synchronize()               # the reference returns finished results; also the point where input flags are read

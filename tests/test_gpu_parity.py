@@ -346,3 +346,182 @@ def test_sampling_driver_layout_and_equivalence():
     ref_pos = r["pos"].cpu().numpy().astype(np.float64)
     assert np.array_equal(ref_pos[:9], pos[0]) and np.array_equal(ref_pos[9:], pos[1])
     assert np.array_equal(r["v"].cpu().numpy()[:9], v[0])
+
+
+# ---- round 2: BASELINE.json configs at full size against reference-generated fixtures ------------------
+def _golden_chain(m, c, atoms_range=None, max_atoms=None):
+    B, S, seed, every, head = int(c["B"]), int(c["S"]), int(c["seed"]), int(c["every"]), int(c["head"])
+    bb = synth.synthetic_batch(B, seed=seed, atoms_range=atoms_range, max_atoms=max_atoms)
+    assert np.array_equal(bb["counts"], c["counts"])
+    eps, u = hash_noise(len(bb["batch"]), S, seed)
+    r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u, use_graph=True)
+    pos_traj, v_traj = torch.stack(r["pos_traj"]), torch.stack(r["v_traj"]).numpy()
+    errs = dict(B=B, S=S, n_atoms=len(bb["batch"]),
+                pos_end=maxabs(r["pos"], c["pos"]), pos_snapshots=maxabs(pos_traj[::every], c["pos_traj_sub"]),
+                pos_head=maxabs(pos_traj[:head], c["pos_traj_head"]), pos0_first=maxabs(r["pos_cond_traj"][0], c["pos0_first"]),
+                v0_first=maxabs(r["v0_traj"][0], c["v0_first"]), vt_last=maxabs(r["vt_traj"][-1], c["vt_last"]),
+                v_mismatch_end=int((r["v"].cpu().numpy() != c["v"]).sum()),
+                v_mismatch_snapshots=int((v_traj[::every] != c["v_traj_sub"]).sum()))
+    k200 = min(len(c["pos_traj_sub"]), 200 // every + 1)
+    errs["pos_first_200"] = maxabs(pos_traj[::every][:k200], c["pos_traj_sub"][:k200])
+    off = np.concatenate([[0], np.cumsum(bb["counts"])])
+    e = np.abs(r["pos"].cpu().numpy().astype(np.float64) - c["pos"]).max(-1)
+    mol = np.array([e[off[b]:off[b + 1]].max() for b in range(B)])
+    errs["pos_end_median_mol"] = float(np.median(mol))
+    errs["mols_over_1e-4_end"] = int((mol > POS_TOL).sum())
+    return errs
+
+
+def test_chain_b256_s1000_golden():
+    """BASELINE configs[1] at full length, free-running: 256 molecules x 1000 reverse steps (graph replay) against the
+    REFERENCE's own run on the same noise.  Atom types must be exact at every snapshot and at the end; coordinates must
+    agree within 1e-4 for every atom until the first kNN near-tie flips a neighbour (measured: after step 200; see
+    test_chain_b256_s1000_windows_golden for why the free-running tail cannot be held to 1e-4 by ANY second float32
+    implementation, and for the gate that covers all 1000 steps).  The tail is recorded, and bounded loosely."""
+    from util import record
+    errs = _golden_chain(hip_model(), golden("chain_b256_s1000_hash.npz"), max_atoms=38)
+    record("chain_b256_s1000_golden", **errs)
+    assert errs["v_mismatch_end"] == 0 and errs["v_mismatch_snapshots"] == 0, errs
+    assert errs["pos_head"] < POS_TOL and errs["pos_first_200"] < POS_TOL, errs
+    assert errs["pos_end_median_mol"] < 5e-4, errs           # the bulk of the molecules stays on the reference's trajectory
+
+
+def test_chain_b1024_s50_golden():
+    """BASELINE configs[2] batch size (1024 molecules, <= 38 atoms): 50 reverse steps against the reference."""
+    from util import record
+    errs = _golden_chain(hip_model(), golden("chain_b1024_s50_hash.npz"), max_atoms=38)
+    record("chain_b1024_s50_golden", **errs)
+    assert errs["v_mismatch_end"] == 0 and errs["v_mismatch_snapshots"] == 0, errs
+    assert errs["pos_end"] < POS_TOL and errs["pos_snapshots"] < POS_TOL, errs
+
+
+def test_forward_b1024_vs_oracle():
+    """B = 1024 (~22k atoms): the multi-job instantiation of the edge kernels at its natural size."""
+    from util import record
+    m = hip_model()
+    sd, dm, _, _ = oracle_model()
+    bb = synth.synthetic_batch(1024, seed=14, max_atoms=38)
+    t = (synth.hash_u24(1024, 9, 14) % 1000).astype(np.int64)
+    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    with torch.no_grad():
+        out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
+    errs = {k: maxabs(out[k], ref[k]) for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v")}
+    record("forward_b1024_vs_oracle", n_atoms=len(bb["batch"]), **errs)
+    assert max(errs.values()) < FWD_TOL, errs
+
+
+@pytest.mark.parametrize("B", [48, 200])
+def test_vn_grid_barrier_many_workgroups(B):
+    """vn_fuse = 1 (coordinate update behind an in-kernel grid barrier) with more workgroups than batch-norm replicas,
+    at 4 waves per workgroup (B = 48) and at the 256-molecule scale: the barrier epilogue's LDS staging must fit."""
+    m = hip_model()
+    sd, dm, _, _ = oracle_model()
+    bb = synth.synthetic_batch(B, seed=41)
+    t = np.full(B, 450, np.int64)
+    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    try:
+        m.set_option("vn_fuse", 1)
+        with torch.no_grad():
+            out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
+        m.check_status()
+    finally:
+        m.set_option("vn_fuse", 2)
+    for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+        assert maxabs(out[k], ref[k]) < FWD_TOL, k
+
+
+def test_invalid_inputs_are_reported():
+    """Unsorted / out-of-range batch vector, atom type or time step: flagged on the device, raised at check_status
+    (the reference raises from torch's indexing ops); nothing is read or written out of bounds meanwhile."""
+    from shapemol_amd import _lib
+    m = hip_model()
+    bb = synth.synthetic_batch(4, seed=3)
+    n = len(bb["batch"])
+    t = np.full(4, 10, np.int64)
+
+    def run(batch=bb["batch"], v=bb["init_v"], tt=t):
+        with torch.no_grad():
+            m(T(bb["init_pos"], DEV), T(v, DEV), T(batch, DEV), T(bb["shape"], DEV), T(tt, DEV))
+        m.check_status()
+    run()
+    bad = bb["batch"].copy(); bad[3], bad[n - 2] = bad[n - 2], bad[3]
+    with pytest.raises(_lib.ShapeMolLibraryError, match="batch"):
+        run(batch=bad)
+    bad = bb["batch"].copy(); bad[-1] = 7
+    with pytest.raises(_lib.ShapeMolLibraryError, match="batch"):
+        run(batch=bad)
+    badv = bb["init_v"].copy(); badv[0] = 15
+    with pytest.raises(_lib.ShapeMolLibraryError, match="atom type"):
+        run(v=badv)
+    with pytest.raises(_lib.ShapeMolLibraryError, match="time step"):
+        run(tt=np.full(4, 1000, np.int64))
+    run()          # flags are per call: a good call afterwards is clean
+
+
+def test_new_seed_and_buffers_replay_the_captured_graph():
+    """The captured step graph depends on the batch geometry only: chains with other seeds, other noise buffers and
+    other trajectory buffers must not re-capture (round 1 re-captured ~400 kernel nodes per new seed)."""
+    m = hip_model()
+    bb = synth.synthetic_batch(16, seed=6)
+    args = (T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV).view(16, -1))
+    m.sample_diffusion(*args, num_steps=10, center_pos_mode="none", seed=1)
+    c0 = int(m.debug_read("captures", (1,), np.int64)[0])
+    r2 = m.sample_diffusion(*args, num_steps=10, center_pos_mode="none", seed=2)
+    eps, u = hash_noise(len(bb["batch"]), 10, 6)
+    m.sample_diffusion(*args, num_steps=10, center_pos_mode="none", noise=(T(eps, DEV), T(u, DEV)), return_traj=False)
+    r2b = m.sample_diffusion(*args, num_steps=10, center_pos_mode="none", seed=2)
+    assert int(m.debug_read("captures", (1,), np.int64)[0]) == c0
+    assert torch.equal(r2["v"], r2b["v"]) and maxabs(r2["pos"], r2b["pos"]) < 1e-6
+
+
+def test_chain_b256_s1000_windows_golden():
+    """The full 1000 steps at B = 256 in twenty 50-step windows, each started from the REFERENCE's state at the window's
+    first step and compared with the reference's state 50 steps later.
+
+    Why windows: kNN neighbour selection is discontinuous, so two float32 implementations that differ by 1e-7 pick a
+    different 8th neighbour whenever two candidates are closer than that (measured: ~20 such molecules per 1000 steps
+    at this size, kNN margins 1e-8 .. 2e-6, profiles/r02/chain_divergence.json), after which that molecule follows a
+    different trajectory and, through the train-mode batch-norm, nudges every other molecule.  A free-running 1000-step
+    comparison therefore measures the flip lottery, not the kernels (test_chain_b256_s1000_golden reports it).  Windows
+    bound the damage of a flip to its own window and molecule, which the test then has to justify one by one:
+    a molecule may exceed 1e-4 only if a neighbour near-tie (relative margin < 1e-5) occurred on its way."""
+    from util import record
+    from tools_knn import knn_margin_rel
+    m = hip_model()
+    c = golden("chain_b256_s1000_hash.npz")
+    B, S, seed, every = int(c["B"]), int(c["S"]), int(c["seed"]), int(c["every"])
+    bb = synth.synthetic_batch(B, seed=seed, max_atoms=38)
+    n = len(bb["batch"])
+    off = np.concatenate([[0], np.cumsum(bb["counts"])])
+    eps, u = hash_noise(n, S, seed)
+    eps_d, u_d = T(eps, DEV), T(u, DEV)
+    batch_d, shape_d = T(bb["batch"], DEV), T(bb["shape"], DEV).view(B, -1)
+    # snapshot j of the fixture = state AFTER reverse step j * every (j = 0 .. S / every - 1); c["pos"] = after step S - 1.
+    # windows: (start state, first step, steps, target state)
+    n_snap = S // every
+    wins = [(bb["init_pos"], bb["init_v"], 0, 1, c["pos_traj_sub"][0], c["v_traj_sub"][0])]
+    for j in range(1, n_snap):
+        wins.append((c["pos_traj_sub"][j - 1], c["v_traj_sub"][j - 1], (j - 1) * every + 1, every, c["pos_traj_sub"][j], c["v_traj_sub"][j]))
+    last = (n_snap - 1) * every
+    wins.append((c["pos_traj_sub"][-1], c["v_traj_sub"][-1], last + 1, S - 1 - last, c["pos"], c["v"]))
+    assert sum(w[3] for w in wins) == S
+    worst_clean, flagged, v_bad = 0.0, [], 0
+    for w, (pos0, v0, s0, ns, ref_pos, ref_v) in enumerate(wins):
+        r = m.sample_diffusion(T(pos0, DEV), T(v0.astype(np.int64), DEV), batch_d, shape_d, num_steps=ns, center_pos_mode="none",
+                               noise=(eps_d[s0:s0 + ns].contiguous(), u_d[s0:s0 + ns].contiguous()), first_step=s0)
+        err = np.abs(r["pos"].cpu().numpy().astype(np.float64) - ref_pos).max(-1)
+        mol_err = np.array([err[off[b]:off[b + 1]].max() for b in range(B)])
+        v_bad += int((r["v"].cpu().numpy() != ref_v.astype(np.int64)).sum())
+        traj = torch.stack(r["pos_traj"]).numpy()
+        for b in np.where(mol_err > POS_TOL)[0]:
+            states = [pos0[off[b]:off[b + 1]]] + [traj[s, off[b]:off[b + 1]] for s in range(ns - 1)]   # inputs of the window's forwards
+            margin = min(knn_margin_rel(x, 8) for x in states)
+            flagged.append(dict(window=w, first_step=s0, mol=int(b), err=float(mol_err[b]), min_knn_margin_rel=float(margin)))
+        clean = mol_err[mol_err <= POS_TOL]
+        worst_clean = max(worst_clean, float(clean.max()) if len(clean) else 0.0)
+    record("chain_b256_s1000_windows_golden", windows=len(wins), worst_unflagged=worst_clean, atom_type_mismatches=v_bad,
+           flagged=flagged)
+    assert v_bad == 0
+    assert worst_clean < POS_TOL
+    assert len(flagged) <= 40, flagged                       # ~1 per window expected
+    assert all(f["min_knn_margin_rel"] < 1e-5 for f in flagged), flagged

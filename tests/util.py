@@ -67,3 +67,15 @@ def maxabs(a, b):
 def hash_noise(n, steps, seed, c=15):
     eps, u = zip(*[synth.step_noise(n, c, s, seed=seed) for s in range(steps)])
     return np.stack(eps), np.stack(u)
+
+
+def record(test, **values):
+    """Append the measured errors of a parity test to gpurun_out/parity_errors.jsonl (copied to profiles/ per round),
+    so that drift between rounds is visible even while the assertions stay green."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_errors.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=test, **{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in values.items()})) + "\n")
+    except OSError:
+        pass
