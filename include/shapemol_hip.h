@@ -122,7 +122,8 @@ int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, co
  *                        state given as d_init_pos / d_init_v; noise and trajectory rows stay indexed from 0; default 0.
  *                        Used by the windowed full-length parity test; the reference always starts at T-1),
  *          "stop_layer" (run only the first v layers of the next _score; -1 = all),
- *          "edge_bf16"  (1 = fused key/value edge kernel with exactly split bf16 second Linears [default],
+ *          "edge_bf16"  (3 = fused key/value edge kernel on two-piece f16 operands, both MLP images resident [default];
+ *                        1 = fused kernel on exactly split bf16 operands (six products, weight swap between the phases),
  *                        2 = the same arithmetic as separate key / value launches, 0 = fp32-MFMA edge kernels;
  *                        k > 16 always uses the fp32 kernels),
  *          "lin_bf16", "chain_bf16" (1 = node kernels on the bf16 matrix cores with exactly split operands

@@ -11,6 +11,8 @@ if [[ "${1:-}" == "--report" ]]; then
    | c++filt | cut -c1-160
 elif [[ "${1:-}" == "--ablate" ]]; then     # diagnostic: drop phases of the edge kernel at compile time (mask in $2)
   hipcc $FLAGS -DSM_ABLATE=$2 -o ../libshapemol_hip_abl$2.so shapemol_hip.hip
+elif [[ "${1:-}" == "--stamps-serial" ]]; then
+  hipcc $FLAGS -DSM_STAMPS -DSM_STAMPS_SERIAL -o ../libshapemol_hip_stamps.so shapemol_hip.hip
 elif [[ "${1:-}" == "--stamps" ]]; then     # diagnostic build with in-kernel phase stamps (tools/ only)
   hipcc $FLAGS -DSM_STAMPS -o ../libshapemol_hip_stamps.so shapemol_hip.hip
 else

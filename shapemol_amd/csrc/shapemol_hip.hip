@@ -6,6 +6,7 @@
 #include "sm_device.h"
 #include "sm_edge.h"
 #include "sm_edge_bf16.h"
+#include "sm_edge16.h"
 #include "sm_node.h"
 #include "sm_misc.h"
 #include <hip/hip_ext.h>
@@ -125,6 +126,7 @@ struct DevLayer {
     DevMlpImg q_x2h, q_h2x, no;
     size_t blob_x2h, blob_h2x;        // fp32 edge kernels (sm_edge.h): both MLPs of a kernel in one LDS image
     size_t img_kx, img_vx, img_kh, img_vh;   // bf16-split phase kernels (sm_edge_bf16.h): one image per MLP
+    size_t i16_kx, i16_vx, i16_kh, i16_vh;   // two-piece f16 images (sm_edge16.h)
     size_t vn_f, vn_d;                // original [heads][cin]
     size_t wf_x, wd_x, wf_o, wd_o, bn_g, bn_b;
 };
@@ -269,6 +271,63 @@ size_t pack_phase_image(Image &im, const Mlp &m, int kv_in, bool perm_heads) {
     return o;
 }
 
+// hi + lo two-piece f16 split (both round-to-nearest): the 16-bit patterns
+void split2_host(float w, uint16_t (&p)[2]) {
+    const _Float16 h = (_Float16)w;
+    const _Float16 l = (_Float16)(w - (float)h);
+    std::memcpy(&p[0], &h, 2);
+    std::memcpy(&p[1], &l, 2);
+}
+
+// one edge MLP -> EdgeImage16 (sm_edge16.h); returns the largest |hidden activation| the LayerNorm of this MLP can
+// produce (the fp16 range check of the caller)
+template <int H>
+float pack_image16(Image &im, const Mlp &m, int kv_in, bool perm_heads, size_t &img) {
+    constexpr int NT = H / 16, NB = NT / 2;
+    const int nt2 = perm_heads ? 1 : NT;
+    const int o_w1 = 0, o_w2 = 2 * NT * 192, o_g = o_w2 + 2 * nt2 * NB * 256, o_b = o_g + H, o_b2 = o_b + H;
+    const int total = (o_b2 + nt2 * 16 + 255) / 256 * 256;
+    img = im.alloc(total);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&im.d[img]);
+    for (int t = 0; t < NT; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int q = 0; q < 3; ++q) {
+                uint16_t pc[2][2];
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * q + e;
+                    split2_host(j < 5 ? m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * j + (lane >> 4)] : 0.f, pc[e]);
+                }
+                for (int piece = 0; piece < 2; ++piece)
+                    d[o_w1 + ((size_t)(piece * NT + t) * 3 + q) * 64 + lane] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+            }
+    for (int t2 = 0; t2 < nt2; ++t2)
+        for (int b = 0; b < NB; ++b)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int mrow = lane & 15, g = lane >> 4;
+                const int row = perm_heads ? head_of_row(mrow, NT) : 16 * t2 + mrow;
+                for (int q = 0; q < 4; ++q) {
+                    uint16_t pc[2][2];
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * q + e;
+                        const int col = 16 * (2 * b + (j >> 2)) + 4 * g + (j & 3);
+                        split2_host(row < 0 ? 0.f : m.l2.w[(size_t)row * H + col], pc[e]);
+                    }
+                    for (int piece = 0; piece < 2; ++piece)
+                        d[o_w2 + (((size_t)(piece * nt2 + t2) * NB + b) * 64 + lane) * 4 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+                }
+            }
+    float *pp = &im.d[img];
+    std::memcpy(pp + o_g, m.g, H * sizeof(float));
+    std::memcpy(pp + o_b, m.be, H * sizeof(float));
+    for (int i = 0; i < nt2 * 16; ++i) {
+        const int row = perm_heads ? head_of_row(i, NT) : i;
+        pp[o_b2 + i] = row < 0 ? 0.f : m.l2.b[row];
+    }
+    float gmax = 0.f, bmax = 0.f;
+    for (int i = 0; i < H; ++i) { gmax = std::max(gmax, std::fabs(m.g[i])); bmax = std::max(bmax, std::fabs(m.be[i])); }
+    return gmax * std::sqrt((float)(H - 1)) + bmax;
+}
+
 // fp32 A-fragment image of W[rows][K] (pack_image) -> split bf16 image of node_linear6_kernel:
 //   [(((ot * 3 + piece) * NB + b) * 64 + lane) * 4 + q] u32, element order of gemm_bf16x6
 size_t pack_linear6_image(Image &im, size_t src, int rows, int K) {
@@ -291,7 +350,7 @@ size_t pack_linear6_image(Image &im, size_t src, int rows, int K) {
 }
 
 template <int H>
-int build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D) {
+int build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D, float &hid_max) {
     const int G = c.num_r_gaussian, SL = c.shape_latent_dim, S = c.shape_dim, hd = c.n_heads;
     const int kv = G + 2 * H + SL, cin = 1 + hd + S, NT = H / 16;
     bool contiguous = true;
@@ -330,6 +389,10 @@ int build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, D
     }
     D.img_kx = pack_phase_image<H>(im, L.hk, kv, false); D.img_vx = pack_phase_image<H>(im, L.hv, kv, false);
     D.img_kh = pack_phase_image<H>(im, L.xk, kv, false); D.img_vh = pack_phase_image<H>(im, L.xv, kv, true);
+    hid_max = std::max(hid_max, pack_image16<H>(im, L.hk, kv, false, D.i16_kx));
+    hid_max = std::max(hid_max, pack_image16<H>(im, L.hv, kv, false, D.i16_vx));
+    hid_max = std::max(hid_max, pack_image16<H>(im, L.xk, kv, false, D.i16_kh));
+    hid_max = std::max(hid_max, pack_image16<H>(im, L.xv, kv, true, D.i16_vh));
     D.vn_f = im.put(L.vn_f, (size_t)hd * cin); D.vn_d = im.put(L.vn_d, (size_t)hd * cin);
     D.bn_g = im.put(L.bn_g, hd); D.bn_b = im.put(L.bn_b, hd);
     D.wf_x = im.alloc(hd); D.wd_x = im.alloc(hd); D.wf_o = im.alloc((size_t)hd * 16); D.wd_o = im.alloc((size_t)hd * 16);
@@ -376,7 +439,8 @@ struct shapemol_ctx {
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 1, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
+    int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 3, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
+    float hid_max = 0.f;        // bound of the edge MLPs' hidden activations (LayerNorm outputs): must fit fp16 for edge_bf16 = 3
     int num_cu = 256;
     int first_step = 0;         // option "first_step": the next chains start at reverse step first_step (t = T-1-first_step)
     // profiling
@@ -462,9 +526,6 @@ int set_edge_attr(int KP) {
 #define SETATTR(K)                                                                                                    \
     HIPCHK(hipFuncSetAttribute((const void *)edge_attention_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b0)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_attention_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b1));
-#define SETATTR1(K)                                                                                                   \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_attention_t1_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b0)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_attention_t1_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b1));
 #define SETATTR2(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_K>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_VX>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
@@ -477,11 +538,16 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)node_prologue6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * Chain6Lds<H>::FRAG * 16 + Chain6Lds<H>::PRE * 4)));
     HIPCHK(hipFuncSetAttribute((const void *)node_chain6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain6Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin6Chunk * 3 * H * 32));
-    if (KP == 8) { SETATTR1(8) SETATTR2(8) SETATTR3(8) } else if (KP == 16) { SETATTR1(16) SETATTR2(16) SETATTR3(16) } else { SETATTR(32) }
+#define SETATTR4(K)                                                                                                   \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
+    if (KP == 8) { SETATTR(8) SETATTR2(8) SETATTR3(8) SETATTR4(8) } else if (KP == 16) { SETATTR(16) SETATTR2(16) SETATTR3(16) SETATTR4(16) } else { SETATTR(32) }
+#undef SETATTR4
 #undef SETATTR2
 #undef SETATTR3
 #undef SETATTR
-#undef SETATTR1
     return 0;
 }
 
@@ -493,17 +559,16 @@ static int edge_waves_for(const shapemol_ctx *c, int njobs) {
 }
 
 template <int H, bool H2X>
-int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {
+int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {     // fp32-MFMA edge kernel (option edge_bf16 = 0; k > 16)
     const int KP = c->KP;
     const int apj = KP >= 16 ? 1 : 16 / KP;
     const int njobs = (a.n_atoms + apj - 1) / apj;
-    const int waves = KP <= 16 ? edge_waves_for(c, njobs) : (c->edge_threads > 0 ? c->edge_threads / 64 : 12);
-    const int grid = KP <= 16 ? std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves))
-                              : std::max(1, std::min(c->num_cu, njobs));
+    const int waves = c->edge_threads > 0 ? c->edge_threads / 64 : 12;
+    const int grid = std::max(1, std::min(c->num_cu, njobs));
     const size_t shm = EdgeBlob<H, H2X>::TOTAL * sizeof(float);
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
-    if (KP == 8) LAUNCH(nm, SMK((edge_attention_t1_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
-    else if (KP == 16) LAUNCH(nm, SMK((edge_attention_t1_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    if (KP == 8) LAUNCH(nm, SMK((edge_attention_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else if (KP == 16) LAUNCH(nm, SMK((edge_attention_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     else LAUNCH(nm, SMK((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     return 0;
 }
@@ -534,6 +599,25 @@ int launch_fused(shapemol_ctx *c, hipStream_t s, const EdgeFusedArgs &a) {
     } else {
         if (one) LAUNCH(nm, SMK((edge_fused_kernel<H, 16, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
         else LAUNCH(nm, SMK((edge_fused_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+    }
+    return 0;
+}
+
+template <int H, bool H2X>
+int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
+    const int KP = c->KP, apj = 16 / KP;
+    const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
+    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
+    const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
+                       + (H2X ? (size_t)vn_red_doubles(waves, H / 8) * 8 + (size_t)waves * apj * 48 * 4 : 0);
+    const char *nm = H2X ? "edge_h2x" : "edge_x2h";
+    const bool one = njobs <= grid * waves;      // every wave has at most one job: straight-line instantiation
+    if (KP == 8) {
+        if (one) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
+        else LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+    } else {
+        if (one) LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
+        else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
     }
     return 0;
 }
@@ -654,7 +738,14 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         const DevLayer &Dl = c->dm.layer[l];
         const bool last = (l == nlay - 1), has_next = !last;
         const bool phases = c->edge_bf16 && KP <= 16;
-        if (phases && c->edge_bf16 == 1) {   // x2h attention, key and value phase in one launch
+        const bool f16 = phases && c->edge_bf16 == 3;     // two-piece f16 operands (sm_edge16.h), the default
+        if (f16) {   // x2h attention: both MLP images resident, one barrier
+            Edge16Args ea{};
+            ea.image_k = c->P(Dl.i16_kx); ea.image_v = c->P(Dl.i16_vx);
+            ea.pre = l == 0 ? c->pre0 : c->preAB + 4 * H; ea.q = c->q_x; ea.x = cur_x; ea.nbr = c->nbr; ea.ew = c->ew; ea.out = c->att;
+            ea.n_atoms = n; ea.ld_pre = l == 0 ? 4 * H : 8 * H; ea.stamps = (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr;
+            if (launch_edge16<H, false>(c, s, ea)) return 1;
+        } else if (phases && c->edge_bf16 == 1) {   // x2h attention, key and value phase in one launch
             EdgeFusedArgs fa{c->P(Dl.img_kx), c->P(Dl.img_vx), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew,
                              c->alpha, c->att, n, l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
             if (launch_fused<H, false>(c, s, fa)) return 1;
@@ -692,7 +783,19 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         }
         float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
         bool vn_done = false, stats_done = false;
-        if (phases && c->edge_bf16 == 1) {   // h2x attention, both images resident in LDS
+        if (f16 && c->vn_fuse != 1) {   // h2x attention (+ VN-linear and batch statistics when vn_fuse = 2)
+            Edge16Args ea{};
+            ea.image_k = c->P(Dl.i16_kh); ea.image_v = c->P(Dl.i16_vh);
+            ea.pre = c->preAB; ea.q = c->q_h; ea.x = cur_x; ea.nbr = c->nbr; ea.ew = c->ew; ea.out = c->o3;
+            ea.n_atoms = n; ea.ld_pre = 8 * H; ea.stamps = (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr;
+            if (c->vn_fuse) {
+                ea.vn = {c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o), c->P(Dl.wd_o),
+                         c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd,
+                         nullptr, c->status + ST_VN_BARRIER, x_next, 2};
+                stats_done = true;
+            }
+            if (launch_edge16<H, true>(c, s, ea)) return 1;
+        } else if (phases && c->edge_bf16 != 2) {   // h2x attention, both images resident in LDS
             EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H,
                              (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
             if (c->vn_fuse) {   // VN-linear + batch statistics (2) or the whole coordinate update (1: grid barrier inside) behind the attention
@@ -814,8 +917,8 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
     }
     dm.layer.resize(cfg->num_layers);
     for (int l = 0; l < cfg->num_layers; ++l) {
-        if (H == 128 ? build_layer_image<128>(*cfg, hm.layer[l], im, dm.layer[l])
-                     : build_layer_image<32>(*cfg, hm.layer[l], im, dm.layer[l])) { delete c; return 1; }
+        if (H == 128 ? build_layer_image<128>(*cfg, hm.layer[l], im, dm.layer[l], c->hid_max)
+                     : build_layer_image<32>(*cfg, hm.layer[l], im, dm.layer[l], c->hid_max)) { delete c; return 1; }
     }
     for (int l = 0; l < cfg->num_layers; ++l) {      // paired images: pre_h2x(l) | pre_x2h(l + 1)
         const size_t blk = (size_t)4 * H * H;
@@ -838,6 +941,7 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
         hipLaunchKernelGGL(time_table_kernel, dim3((T + 63) / 64), dim3(64), 0, nullptr, ta);
         if (hipDeviceSynchronize() != hipSuccess) { hipFree(c->ttab); hipFree(c->d_img); delete c; return fail("time table kernel failed"); }
     }
+    if (c->hid_max > 6.0e4f) c->edge_bf16 = 1;      // hidden activations could overflow fp16: exactly split bf16 kernels
     *out = c;
     return 0;
 }
@@ -960,7 +1064,10 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
         return 0;
     }
     if (k == "stop_layer") c->stop_layer = (int)value;
-    else if (k == "edge_bf16") c->edge_bf16 = (int)value;
+    else if (k == "edge_bf16") {
+        if (value == 3 && c->hid_max > 6.0e4f) return fail("edge_bf16 = 3: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights");
+        c->edge_bf16 = (int)value;
+    }
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "chain_bf16") c->chain_bf16 = (int)value;
     else if (k == "vn_fuse") c->vn_fuse = (int)value;

@@ -69,6 +69,19 @@ SM_DEV void copy_to_lds(float *lds, const float *g, int n4, int tid, int nthr) {
     for (; i < n4; i += nthr) dst[i] = src[i];
 }
 
+// Asynchronous global -> LDS copy of `n4` float4 (a multiple of 64: whole 1 KB pieces) by LDS-DMA: every wave issues
+// its share of the pieces back to back (global_load_lds_dwordx4: wave-uniform LDS base + 16 bytes per lane, per-lane
+// source address) and carries on; nothing is staged in registers.  The data has landed after the issuing wave's
+// s_waitcnt vmcnt(0) -- which __syncthreads() includes -- and the barrier.  (copy_to_lds above falls back to one
+// dependent load -> store round per 12 KB for images smaller than its unrolled round: 7 us for 160 KB.)
+SM_DEV void dma_to_lds(float *lds, const float *g, int n4, int wave, int nwave, int lane) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    for (int c = wu; c < n4 / 64; c += nwave)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(g + ((size_t)c * 64 + lane) * 4), (lds_void *)(lds + (size_t)c * 256), 16, 0, 0);
+}
+
 // ---- cross-lane helpers without LDS traffic ------------------------------------------------------
 // DPP row operations (within a 16-lane row) and the gfx950 permlane swaps (between rows); a
 // __shfl_xor would lower to ds_bpermute_b32 (LDS pipe, ~100+ cycles of latency each).

@@ -242,237 +242,3 @@ edge_attention_kernel(EdgeArgs a) {
         SM_STAMP(a.stamps, 7);
     }
 }
-
-// -------------------------------------------------------------------------------------------------
-// Single-tile variant (KP <= 16: all neighbour slots of an atom sit in one 16-column tile).
-// With ~2.8k jobs and ~3k wave slots every wave runs one job, so the kernel time IS the latency of
-// one job; this version shortens that critical path: the job's index / coordinate / gather / query
-// loads are issued BEFORE the 154 KB weight image is copied to LDS (their L2 latency hides under the
-// copy), the value-path gathers are issued before the softmax of the key path, and all reductions
-// are DPP / permlane operations.
-// -------------------------------------------------------------------------------------------------
-template <int NT>
-SM_DEV void hidden_from_regs(const float4 (&ga)[NT], const float4 (&gb)[NT], const float (&rb)[5], const float *wr,
-                             const float *gamma, const float *beta, int lane, int g, float (&hid)[NT * 4]) {
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma16(wr[(t * 5 + s) * 64 + lane], rb[s], acc[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
-        hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
-    }
-    ln_relu_dlayout<NT>(hid, gamma, beta, g);
-}
-
-// raw = A_i + B_j + W_r rbf for one tile (first Linear of an edge MLP before its LayerNorm), D layout
-template <int NT>
-SM_DEV void first_linear(const float4 (&ga)[NT], const float4 (&gb)[NT], const float (&rb)[5], const float *wr,
-                         int lane, float (&raw)[NT * 4]) {
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma16(wr[(t * 5 + s) * 64 + lane], rb[s], acc[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        raw[4 * t + 0] = acc[t][0]; raw[4 * t + 1] = acc[t][1];
-        raw[4 * t + 2] = acc[t][2]; raw[4 * t + 3] = acc[t][3];
-    }
-}
-
-#ifndef SM_INTERLEAVE
-#define SM_INTERLEAVE 1      // 1: sched_group_barrier pattern MFMA | DS | VALU inside the long MFMA runs
-#endif
-#ifndef SM_ABLATE
-#define SM_ABLATE 0          // diagnostic builds only: compile-time mask of phases to drop (timing attribution)
-#endif
-#define SM_ABL(bit) (((SM_ABLATE) >> (bit)) & 1)
-
-template <int H, int KP, bool H2X>
-__global__ void __launch_bounds__(768)
-edge_attention_t1_kernel(EdgeArgs a) {
-    static_assert(KP == 8 || KP == 16, "single-tile variant");
-    using BL = EdgeBlob<H, H2X>;
-    constexpr int NT = BL::NT;
-    constexpr int NT2V = BL::NT2V;
-    constexpr int APJ = 16 / KP;
-    constexpr int SEGW = KP;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int n = lane & 15, g = lane >> 4;
-    float cen[5];
-    rbf_centres(g, cen);
-    const int njobs = (a.n_atoms + APJ - 1) / APJ;
-    const int jstride = gridDim.x * nwave;
-    const float inv_sqrt_dh = 0.35355339059327373f;   // 1/sqrt(8)
-
-    // consecutive jobs per workgroup: its waves then work on the atoms of one or two molecules and the
-    // neighbour rows they gather (each row is wanted by ~k different edges) are shared through the CU's L1
-    int job = blockIdx.x * nwave + wave;
-    bool have = job < njobs;
-    // per-job state loaded ahead of use
-    int atom = 0, jn = 0;
-    bool atom_ok = false, ok = false;
-    float xi[3], xj[3], ewv = 0.f;
-    float4 ga[NT], gb[NT], qv[NT];
-
-    auto issue_loads = [&](int jb) {
-        const int atom_raw = jb * APJ + n / SEGW;
-        atom_ok = atom_raw < a.n_atoms;
-        atom = atom_ok ? atom_raw : a.n_atoms - 1;
-        const int slot = n % SEGW;
-        const int jraw = a.nbr[atom * KP + slot];
-        ok = atom_ok && jraw >= 0;
-        jn = ok ? jraw : atom;
-        ewv = a.ew[atom * KP + slot];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { xi[k] = a.x[atom * 3 + k]; xj[k] = a.x[jn * 3 + k]; }
-        const float *pi = a.pre + (size_t)atom * a.ld_pre, *pj = a.pre + (size_t)jn * a.ld_pre + H;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if constexpr (SM_ABL(3)) { ga[t] = float4{0.1f * xi[0], 0.2f, 0.3f, 0.4f * xj[1]}; gb[t] = ga[t]; }
-            else { ga[t] = ldg4(pi + 16 * t + 4 * g); gb[t] = ldg4(pj + 16 * t + 4 * g); }
-        }
-    };
-    SM_TICK(a.stamps, 0);
-    if (have) issue_loads(job);
-    if constexpr (!SM_ABL(5)) copy_to_lds(lds, a.blob, BL::TOTAL / 4, threadIdx.x, blockDim.x);
-    __syncthreads();
-    if constexpr (SM_ABL(6)) { if (have && xi[0] == 1.2345f) a.out[0] = ga[0].x + gb[1].y + ewv; return; }
-    SM_TICK(a.stamps, 1);
-
-    while (have) {
-        // keep the loop-invariant LDS weight reads inside the loop (see edge_attention_kernel)
-        asm volatile("" ::: "memory");
-        const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
-        const float d = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
-        float rb[5];
-        rbf_dlayout(d, cen, rb);
-        // The key and value MLPs are independent until alpha * v, so the wave's instruction stream is laid
-        // out to give every long MFMA run independent vector work to issue underneath it (waves of a SIMD
-        // run the same phases in lockstep, so VALU-only stretches would otherwise leave the matrix pipe idle):
-        //   first Linear of both MLPs | LN_k | second Linear k  ||  LN_v | second Linear v  ||  logits + softmax | tail
-        float hid_k[NT * 4], hid_v[NT * 4];
-        first_linear<NT>(ga, gb, rb, lds + BL::K_WR, lane, hid_k);
-        {   // value-path gathers: ga/gb are free again
-            const float *pi = a.pre + (size_t)atom * a.ld_pre + 2 * H, *pj = a.pre + (size_t)jn * a.ld_pre + 3 * H;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if constexpr (!SM_ABL(3)) { ga[t] = ldg4(pi + 16 * t + 4 * g); gb[t] = ldg4(pj + 16 * t + 4 * g); }
-            }
-        }
-        ln_relu_dlayout<NT>(hid_k, lds + BL::K_G, lds + BL::K_B, g);
-        SM_TICK(a.stamps, 2);
-        first_linear<NT>(ga, gb, rb, lds + BL::V_WR, lane, hid_v);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { if constexpr (SM_ABL(3)) qv[t] = float4{0.1f, 0.1f, 0.1f, 0.1f}; else qv[t] = ldg4(a.q + (size_t)atom * H + 16 * t + 4 * g); }
-        f32x4 kacc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 b2 = ldg4(lds + BL::K_B2 + 16 * t + 4 * g);
-            kacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
-        }
-        // ---- second Linear of the key path, with the value path's LayerNorm issued in its shadow
-        if constexpr (!SM_ABL(0)) gemm_packed<NT, NT>(lds + BL::K_W2, hid_k, kacc, lane);
-        ln_relu_dlayout<NT>(hid_v, lds + BL::V_G, lds + BL::V_B, g);
-        if constexpr (SM_INTERLEAVE) {
-#pragma unroll
-            for (int i = 0; i < NT * NT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
-            }
-        }
-        SM_TICK(a.stamps, 3);
-        f32x4 vacc[NT2V];
-#pragma unroll
-        for (int t = 0; t < NT2V; ++t) {
-            const float4 b2 = ldg4(lds + BL::V_B2 + 16 * t + 4 * g);
-            vacc[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
-        }
-        // ---- second Linear of the value path, with the logits / softmax of the key path in its shadow
-        if constexpr (!SM_ABL(0)) gemm_packed<NT, NT2V>(lds + BL::V_W2, hid_v, vacc, lane);
-        float alpha[NT];
-        // logit of head 2t + (g >> 1): 4 dims here + 4 dims in the partner lane group (g ^ 1)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float p = qv[t].x * kacc[t][0] + qv[t].y * kacc[t][1] + qv[t].z * kacc[t][2] + qv[t].w * kacc[t][3];
-            p = sum_xor16(p);
-            p = ok ? p * inv_sqrt_dh : -INFINITY;
-            const float mx = seg_max<SEGW>(p);
-            const float e = ok ? expf(p - mx) : 0.f;
-            const float s = seg_sum<SEGW>(e);
-            alpha[t] = s > 0.f ? e / s : 0.f;
-        }
-        if constexpr (SM_INTERLEAVE) {
-#pragma unroll
-            for (int i = 0; i < NT * NT2V; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x002, H2X ? 24 : 5, 1);
-            }
-        }
-        SM_TICK(a.stamps, 4);
-        const float w = ok ? ewv : 0.f;
-        {
-            SM_TICK(a.stamps, 6);
-            const int out_atom = atom;
-            const bool out_ok = atom_ok && (n % SEGW) == 0;
-            job += jstride;
-            have = job < njobs;
-            if constexpr (!H2X) {
-                float o[NT * 4];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float aw = alpha[t] * w;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[4 * t + r] = seg_sum<SEGW>(aw * vacc[t][r]);
-                }
-                if (out_ok) {
-                    float *op = a.out + (size_t)out_atom * H;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        stg4(op + 16 * t + 4 * g, float4{o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]});
-                }
-                if (have) issue_loads(job);
-            } else {
-                // value row 4g + r belongs to head 2*((NT/2)*(g&1) + r) + (g>>1), whose alpha this lane
-                // holds in alpha[(NT/2)*(g&1) + r]; rows with r >= NT/2 are zero padding.
-                float o[12];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // both candidates are formed and one is selected, so that `alpha` stays in registers
-                    // (a select between two array elements is turned into a dynamically indexed stack array)
-                    float av = 0.f;
-                    if (r < NT / 2) {
-                        const float av_lo = alpha[r] * w * vacc[0][r];
-                        const float av_hi = alpha[(NT / 2 + r) % NT] * w * vacc[0][r];
-                        av = (g & 1) ? av_hi : av_lo;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) o[3 * r + k] = seg_sum<SEGW>(av * rel[k]);
-                }
-                if (out_ok) {
-                    float *op = a.out + (size_t)out_atom * 48 + 12 * g;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        stg4(op + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
-                }
-                if (have) issue_loads(job);
-            }
-        }
-        SM_TICK(a.stamps, 7);
-    }
-}

@@ -1,0 +1,377 @@
+// Edge attention with both Linears of the edge MLPs as THREE f16 MFMA products of two-piece operands (the default
+// kernels).  Same semantics and formulation as sm_edge_bf16.h (reference: models/uni_transformer.py:48-81 for x2h,
+// :121-151 for h2x); what changes is the arithmetic of the matrix products and, through it, the kernel's structure:
+//
+//   * a float is carried as hi + lo with hi = f16(x), lo = f16(x - hi), both round-to-nearest: 22 significand bits
+//     (|x - hi - lo| <= 2^-22 |x|, typically 2^-23), and x * w = hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with
+//     fp32 accumulation (the dropped lo*lo term is < 2^-22 |x w|).  That is three matrix instructions per product where
+//     the exactly split bf16 pieces (8 + 8 + 8 bits) need six, at an error per term that stays below the rounding of
+//     the fp32 accumulation of a 128-term sum.  fp16 subnormal pieces are honoured by the matrix cores
+//     (profiles/r02/mfma_f16_probe.txt), so small activations keep an absolute error of 2^-25; the operands are bounded
+//     by construction: Gaussian smearing values lie in [0, 1], hidden activations are LayerNorm outputs
+//     (|y| <= |gamma| sqrt(H - 1) + |beta|, checked against the fp16 range when the context is created), weights are
+//     below 1.
+//   * two-piece weights take 4 bytes per element: the LDS images of BOTH edge MLPs of an attention fit together
+//     (2 x 78 KB at H = 128 for x2h; the RBF block of the first Linear is stored without the zero word of its K = 20 -> 32
+//     padding, which is what leaves room for the LayerNorm parameters and biases).  The images arrive by LDS-DMA
+//     (global_load_lds_dwordx4, no register staging): no weight swap, one workgroup barrier, and the attention weights go
+//     from the key phase to the value phase in registers (v_permlane16_swap) instead of through a global scratch array.
+//
+// One job = the KP <= 16 neighbour slots of 16 / KP centre atoms = one 16-column tile; a wave runs the key MLP and
+// then the value MLP of its job.  Layouts as in sm_device.h (D layout; the accumulator of one product is the B operand
+// of the next).
+#pragma once
+#include "sm_device.h"
+#include "sm_edge_bf16.h"      // EdgeFusedArgs::VnFuse, kVnReplicas, vn_red_doubles
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+SM_DEV f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// two floats -> {hi pair, lo pair}, each one u32 of two f16 (low half = x0)
+SM_DEV void split2_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
+    const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+    const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+    const f16x2 l = __builtin_convertvector(f32x2{r0, r1}, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// D-layout activations -> B fragments of the NT / 2 k-steps (two pieces each)
+template <int NT>
+SM_DEV void split_act16(const float (&act)[NT * 4], u32x4 (&bh)[NT / 2], u32x4 (&bl)[NT / 2]) {
+#pragma unroll
+    for (int b = 0; b < NT / 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h, l;
+            split2_pair(act[8 * b + 2 * q], act[8 * b + 2 * q + 1], h, l);
+            bh[b][q] = h; bl[b][q] = l;
+        }
+}
+
+// LDS image of ONE edge MLP, in 32-bit words
+//   W1 (RBF block of the first Linear, K = 20 padded to one K = 32 step): 2 pieces x [NT][3][64] u32: word q (two f16) of
+//       lane (m, g) = pieces of W1[16t + m][4j + g], j = 2q, 2q + 1 (j < 5, else 0); the fourth word of the A fragment
+//       (j = 6, 7) is always zero and not stored
+//   W2: 2 pieces x [NT2][NB][64][4] u32; element j of lane (m, g) at k-step b = piece(W2[16 t2 + m][16 (2b + (j >> 2)) + 4g + (j & 3)])
+//   gamma[H] | beta[H] | b2[NT2 * 16] (fp32), padded to a whole 1 KB DMA piece
+template <int H, int NT2>
+struct EdgeImage16 {
+    static constexpr int NT = H / 16, NB = NT / 2;
+    static constexpr int O_W1 = 0;
+    static constexpr int O_W2 = O_W1 + 2 * NT * 192;
+    static constexpr int O_G = O_W2 + 2 * NT2 * NB * 256;
+    static constexpr int O_B = O_G + H;
+    static constexpr int O_B2 = O_B + H;
+    static constexpr int TOTAL = (O_B2 + NT2 * 16 + 255) / 256 * 256;
+};
+
+// acc[t] += W1[:, 0:20] rbf for all NT tiles: one K = 32 step, three products per tile
+template <int NT>
+SM_DEV void first_linear16(const unsigned *w1, u32x4 rh, u32x4 rl, f32x4 (&acc)[NT], int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const unsigned *ph = w1 + (0 * NT + t) * 192 + lane, *pl = w1 + (1 * NT + t) * 192 + lane;
+        const u32x4 ah = {ph[0], ph[64], ph[128], 0u};
+        const u32x4 al = {pl[0], pl[64], pl[128], 0u};
+        f32x4 c = acc[t];
+        c = mfma_f16(al, rh, c);      // smallest terms first
+        c = mfma_f16(ah, rl, c);
+        c = mfma_f16(ah, rh, c);
+        acc[t] = c;
+    }
+}
+
+// one output tile of the second Linear
+template <int NT, int NT2>
+SM_DEV f32x4 tile_f16x3(const unsigned *w2, int t2, const u32x4 (&bh)[NT / 2], const u32x4 (&bl)[NT / 2], f32x4 c, int lane) {
+    constexpr int NB = NT / 2;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const u32x4 ah = *reinterpret_cast<const u32x4 *>(w2 + (((0 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+        const u32x4 al = *reinterpret_cast<const u32x4 *>(w2 + (((1 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+        c = mfma_f16(al, bh[b], c);
+        c = mfma_f16(ah, bl[b], c);
+        c = mfma_f16(ah, bh[b], c);
+    }
+    return c;
+}
+
+struct Edge16Args {
+    const float *image_k, *image_v;   // EdgeImage16 of the key / value MLP
+    const float *pre;       // node pre-products [N][ld_pre]: A_k | B_k | A_v | B_v at column offsets 0, H, 2H, 3H
+    const float *q;         // [N][H]
+    const float *x;         // [N][3]
+    const int *nbr;         // [N][KP]
+    const float *ew;        // [N][KP]
+    float *out;             // x2h: [N][H]; h2x: [N][16][3]
+    int n_atoms, ld_pre;
+    unsigned long long *stamps;       // diagnostic build only
+    EdgeFusedArgs::VnFuse vn;         // h2x: VN-linear + batch statistics behind the attention (enable = 0 or 2)
+};
+
+// ONE = true: every wave has at most one job (jobs <= workgroups x waves; the common case up to ~6k atoms).
+template <int H, int KP, bool H2X, bool ONE = false>
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
+edge16_kernel(Edge16Args a) {
+    static_assert(KP == 8 || KP == 16, "single-tile jobs");
+    constexpr int NT = H / 16;
+    constexpr int NT2V = H2X ? 1 : NT;
+    using IMK = EdgeImage16<H, NT>;
+    using IMV = EdgeImage16<H, NT2V>;
+    constexpr int V_BASE = IMK::TOTAL;
+    constexpr int APJ = 16 / KP, SEGW = KP;
+    constexpr int HD = H / 8;                                     // heads = VN channels
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    float cen[5];
+    rbf_centres(g, cen);
+    const int njobs = (a.n_atoms + APJ - 1) / APJ;
+    const int jstride = gridDim.x * nwave;
+    const int job0 = blockIdx.x * nwave + wave;
+
+    int atom = 0, jn = 0, edge = 0;
+    bool atom_ok = false, ok = false;
+    float xi[3], xj[3];
+    float4 ga[NT], gb[NT], gav[NT], gbv[NT];      // gathered rows: A_k[i], B_k[j], A_v[i], B_v[j]
+    float4 qv[NT];                                // query row of the centre atom
+    float wgt = 0.f;
+
+    // the key MLP's rows are requested up front: the centre atom's first (they do not wait for the neighbour index),
+    // then the neighbour's
+    auto request = [&](int jb) {
+        const int atom_raw = jb * APJ + n / SEGW;
+        atom_ok = atom_raw < a.n_atoms;
+        atom = atom_ok ? atom_raw : a.n_atoms - 1;
+        edge = atom * KP + n % SEGW;
+        const int jraw = a.nbr[edge];
+        const float *pi = a.pre + (size_t)atom * a.ld_pre;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ga[t] = ldg4(pi + 16 * t + 4 * g);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xi[k] = a.x[atom * 3 + k];
+        ok = atom_ok && jraw >= 0;
+        jn = ok ? jraw : atom;
+        const float *pj = a.pre + (size_t)jn * a.ld_pre + H;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gb[t] = ldg4(pj + 16 * t + 4 * g);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xj[k] = a.x[jn * 3 + k];
+        wgt = a.ew[edge];
+    };
+    // the value MLP's rows and the query row are requested once the key rows have been consumed (register budget): they
+    // fly under the key MLP's hidden layer (all of whose other operands come from LDS)
+    auto request_2 = [&]() {
+        const float *pi = a.pre + (size_t)atom * a.ld_pre + 2 * H, *pj = a.pre + (size_t)jn * a.ld_pre + 3 * H;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { gav[t] = ldg4(pi + 16 * t + 4 * g); gbv[t] = ldg4(pj + 16 * t + 4 * g); }
+        const float *qrow = a.q + (size_t)atom * H + 4 * g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qv[t] = ldg4(qrow + 16 * t);
+    };
+    // hidden = ReLU(LN(A_i + B_j + W_r rbf)) -> B fragments
+    auto hidden = [&](const float *img, auto im_tag, const float4 (&ra)[NT], const float4 (&rbw)[NT], u32x4 rh, u32x4 rl,
+                      u32x4 (&bh)[NT / 2], u32x4 (&bl)[NT / 2], auto after_rows) {
+        using IM = decltype(im_tag);
+        float hid[NT * 4];
+        {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = f32x4{ra[t].x + rbw[t].x, ra[t].y + rbw[t].y, ra[t].z + rbw[t].z, ra[t].w + rbw[t].w};
+            after_rows();
+            first_linear16<NT>(reinterpret_cast<const unsigned *>(img) + IM::O_W1, rh, rl, acc, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
+                hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
+            }
+        }
+        ln_relu_dlayout<NT>(hid, img + IM::O_G, img + IM::O_B, g);
+        split_act16<NT>(hid, bh, bl);
+    };
+
+    const bool have0 = job0 < njobs;
+    SM_TICK(a.stamps, 0);
+    // both weight images by LDS-DMA (asynchronous, no register staging); the job's row gathers fly beside them
+    dma_to_lds(lds, a.image_k, IMK::TOTAL / 4, wave, nwave, lane);
+    dma_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, wave, nwave, lane);
+    if (have0) request(job0);
+    __syncthreads();
+    SM_TICK(a.stamps, 1);
+
+    const float *imk = lds, *imv = lds + V_BASE;
+    const unsigned *w2k = reinterpret_cast<const unsigned *>(imk) + IMK::O_W2;
+    const unsigned *w2v = reinterpret_cast<const unsigned *>(imv) + IMV::O_W2;
+    // fused coordinate update (h2x): scratch behind the images
+    double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);
+    float *vn_o = reinterpret_cast<float *>(vn_red + vn_red_doubles(nwave, HD)) + wave * (APJ * 48);   // this wave's attention rows [APJ][16][3]
+    const bool one_job = njobs <= jstride;
+
+    bool first = true;
+    for (int job = job0; job < njobs; job += jstride) {
+        if constexpr (!ONE) asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
+        if (!first) request(job);
+        first = false;
+        const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
+        u32x4 rh = {0u, 0u, 0u, 0u}, rl = {0u, 0u, 0u, 0u};
+        {
+            float rb[5];
+            rbf_dlayout(sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]), cen, rb);
+            unsigned h, l;
+            split2_pair(rb[0], rb[1], h, l); rh[0] = h; rl[0] = l;
+            split2_pair(rb[2], rb[3], h, l); rh[1] = h; rl[1] = l;
+            split2_pair(rb[4], 0.f, h, l); rh[2] = h; rl[2] = l;
+        }
+        // ---- hidden activations of both MLPs, then the two second Linears back to back from registers ----------------
+        u32x4 kh[NT / 2], kl[NT / 2], vh[NT / 2], vl[NT / 2];
+        hidden(imk, IMK{}, ga, gb, rh, rl, kh, kl, request_2);
+        SM_TICK(a.stamps, 2);
+        hidden(imv, IMV{}, gav, gbv, rh, rl, vh, vl, []() {});
+        SM_TICK(a.stamps, 3);
+        // ---- key phase: k -> logits -> softmax over the atom's neighbour slots.  The bias of the key MLP's second Linear
+        //      adds the same q_i . b2 to every neighbour's logit of a head and cancels in the softmax: it is not applied.
+        float alpha[NT / 2];
+        {
+            f32x4 ka = tile_f16x3<NT, NT>(w2k, 0, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+            f32x4 kb = tile_f16x3<NT, NT>(w2k, NT / 2, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+#pragma unroll
+            for (int t = 0; t < NT / 2; ++t) {
+                f32x4 na = ka, nb = kb;
+                if (t + 1 < NT / 2) {
+                    na = tile_f16x3<NT, NT>(w2k, t + 1, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+                    nb = tile_f16x3<NT, NT>(w2k, t + 1 + NT / 2, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+                }
+                alpha[t] = attention_weight_pair<NT, SEGW>(qv[t], qv[t + NT / 2], ka, kb, ok);
+                ka = na; kb = nb;
+            }
+        }
+        SM_TICK(a.stamps, 4);
+        // ---- value phase ----------------------------------------------------------------------------------------------
+        const float w = ok ? wgt : 0.f;
+        const bool store = atom_ok && (n % SEGW) == 0;
+        {
+            const float *b2 = imv + IMV::O_B2;
+            if constexpr (!H2X) {
+                // alpha[t] of lane group g belongs to head block t + (NT/2)(g & 1); output tile T needs head block T of the
+                // lane's group pair: one v_permlane16_swap hands every lane both halves
+                float al[NT];
+#pragma unroll
+                for (int t = 0; t < NT / 2; ++t) {
+                    float lo = alpha[t], hi = alpha[t];
+                    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                    al[t] = lo * w; al[t + NT / 2] = hi * w;
+                }
+                // sum_j a_ij (W2 hid_ij + b2) = sum_j a_ij W2 hid_ij + b2 sum_j a_ij: the bias enters through the per-head sum
+                // of the weights, so the accumulators start at zero and b2 is only needed by the storing lanes at the end
+                float *op = a.out + (size_t)atom * H;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 v = tile_f16x3<NT, NT>(w2v, t, vh, vl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+                    const float4 bb = ldg4(b2 + 16 * t + 4 * g);
+                    const float aw = al[t];
+                    const float sw = seg_sum<SEGW>(aw);
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = seg_sum<SEGW>(aw * v[r]);
+                    if (store) stg4(op + 16 * t + 4 * g, float4{o[0] + sw * bb.x, o[1] + sw * bb.y, o[2] + sw * bb.z, o[3] + sw * bb.w});
+                }
+            } else {
+                const float4 bb = ldg4(b2 + 4 * g);
+                const f32x4 vacc = tile_f16x3<NT, 1>(w2v, 0, vh, vl, f32x4{bb.x, bb.y, bb.z, bb.w}, lane);
+                // value row 4g + r belongs to head 2*((NT/2)*(g&1) + r) + (g>>1) = the head of the lane's own alpha[r]
+                float o[12];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float av = r < NT / 2 ? alpha[r % (NT / 2)] * w * vacc[r] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) o[3 * r + k] = seg_sum<SEGW>(av * rel[k]);
+                }
+                if (store) {
+                    float *op = a.out + (size_t)atom * 48 + 12 * g;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        stg4(op + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
+                    if (a.vn.enable && one_job) {           // keep the rows at hand for the VN-linear below (no L2 round trip)
+                        float *ol = vn_o + (n / SEGW) * 48 + 12 * g;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            stg4(ol + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
+                    }
+                }
+            }
+        }
+        SM_TICK(a.stamps, 5);
+        if constexpr (ONE) break;
+    }
+
+    if constexpr (H2X) {
+        if (!a.vn.enable) return;
+        // ---- VN-linear of this wave's atoms: p, d per channel from the 16 attention rows (+ x, + shape term) and the
+        //      batch sums of ||p|| (shape_vn_layers.py:41-61,95-110): lane = (atom of the job, channel) ----
+        const int v_al = lane >> 4, v_c = lane & 15;
+        const bool v_lane = v_al < APJ && v_c < HD;
+        double v_s1 = 0.0, v_s2 = 0.0;
+        if (!one_job) __syncthreads();               // rows come back through L2: drain this workgroup's stores first
+        for (int jb = job0; jb < njobs; jb += jstride) {
+            const int va = jb * APJ + v_al;
+            if (v_lane && va < a.n_atoms) {
+                float orow[48];
+                const float *ov = one_job ? vn_o + v_al * 48 : a.out + (size_t)va * 48;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const float4 t = ldg4(ov + 4 * i);
+                    orow[4 * i] = t.x; orow[4 * i + 1] = t.y; orow[4 * i + 2] = t.z; orow[4 * i + 3] = t.w;
+                }
+                float wf[16], wd[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 t = ldg4(a.vn.wf_o + v_c * 16 + 4 * i), u = ldg4(a.vn.wd_o + v_c * 16 + 4 * i);
+                    wf[4 * i] = t.x; wf[4 * i + 1] = t.y; wf[4 * i + 2] = t.z; wf[4 * i + 3] = t.w;
+                    wd[4 * i] = u.x; wd[4 * i + 1] = u.y; wd[4 * i + 2] = u.z; wd[4 * i + 3] = u.w;
+                }
+                const float *psf = a.vn.ps + ((size_t)a.vn.mol_of[va] * 2 * HD + v_c) * 3;
+                const float *psd = psf + HD * 3;
+                const float wfx = a.vn.wf_x[v_c], wdx = a.vn.wd_x[v_c];
+                float p[3], d[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float xk = a.x[va * 3 + k];
+                    float pp = wfx * xk, dd = wdx * xk;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        pp += wf[r] * orow[r * 3 + k];
+                        dd += wd[r] * orow[r * 3 + k];
+                    }
+                    p[k] = pp + psf[k];
+                    d[k] = dd + psd[k];
+                }
+                float *out = a.vn.pd + ((size_t)va * HD + v_c) * 6;
+                out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
+                const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
+                v_s1 += (double)nrm;
+                v_s2 += (double)nrm * (double)nrm;
+            }
+        }
+        if (lane < 32) { vn_red[(wave * 32 + lane) * 2] = v_s1; vn_red[(wave * 32 + lane) * 2 + 1] = v_s2; }
+        __syncthreads();
+        if (threadIdx.x < HD) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int w = 0; w < nwave; ++w)
+                for (int al = 0; al < APJ; ++al) {
+                    s1 += vn_red[(w * 32 + al * 16 + threadIdx.x) * 2];
+                    s2 += vn_red[(w * 32 + al * 16 + threadIdx.x) * 2 + 1];
+                }
+            double *acc = a.vn.acc + (size_t)(blockIdx.x % kVnReplicas) * 2 * HD;
+            atomicAdd(acc + threadIdx.x, s1);
+            atomicAdd(acc + HD + threadIdx.x, s2);
+        }
+    }
+}

@@ -70,8 +70,8 @@ def test_forward_b4_golden(name):
         assert maxabs(out[k], f[f"{name}_{k}"]) < FWD_TOL, k
 
 
-@pytest.mark.parametrize("opts", [{"edge_bf16": 0}, {"edge_bf16": 2}, {"lin_bf16": 0, "chain_bf16": 0}, {"vn_fuse": 1}, {"vn_fuse": 0}],
-                         ids=["edge_fp32", "edge_phases", "node_fp32", "vn_grid_barrier", "vn_separate"])
+@pytest.mark.parametrize("opts", [{"edge_bf16": 0}, {"edge_bf16": 1}, {"edge_bf16": 2}, {"lin_bf16": 0, "chain_bf16": 0}, {"vn_fuse": 1}, {"vn_fuse": 0}],
+                         ids=["edge_fp32", "edge_bf16x6", "edge_phases", "node_fp32", "vn_grid_barrier", "vn_separate"])
 def test_forward_alternative_kernels_golden(opts):
     """The optional kernel variants behind shapemol_set_option compute the same forward (ragged batch too)."""
     m = hip_model()
@@ -89,7 +89,7 @@ def test_forward_alternative_kernels_golden(opts):
         assert int(m.debug_read("vn_err", (1,), np.int32)[0]) == 0
     finally:
         for k in opts:
-            m.set_option(k, {"edge_bf16": 1, "lin_bf16": 1, "chain_bf16": 1, "vn_fuse": 2}[k])
+            m.set_option(k, {"edge_bf16": 3, "lin_bf16": 1, "chain_bf16": 1, "vn_fuse": 2}[k])
 
 
 def test_forward_ragged_golden():
