@@ -37,6 +37,9 @@ from shapemol_amd.runtime import ChainRunner  # noqa: E402
 TRAIN_YML = os.path.join(ROOT, "config", "training",
                          "dgcnn_signeddist_512_attention_residue_uniform_pos0_10_pos1.e-7_0.01_6_v001.yml")
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TFLOPS = 2500.0      # dense f16 / bf16 matrix peak (same guide)
+HBM_PEAK_GBS = 8000.0              # HBM3E peak (same guide)
+PROFILE_DIR = "r02_final"          # profiles/<dir>/pmc_traffic*.json hold the PMC traffic of the kernels timed here
 CHAIN_STEPS = 1000                 # the metric is quoted for 1000-step chains
 
 
@@ -82,6 +85,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="molecules per GPU (BASELINE config 2: 256)")
+    ap.add_argument("--atoms", type=str, default="", help="lo,hi: uniform atom counts instead of the MOSES prior (configs[4]: 40,80)")
+    ap.add_argument("--knn", type=int, default=0, help="override the model's k (configs[4]: 32)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--cpu-steps", type=int, default=20, help="reverse steps of the CPU oracle to time (0 = skip)")
     ap.add_argument("--no-traj", action="store_true", help="do not keep per-step trajectories")
@@ -107,13 +112,16 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     cfg = yaml.safe_load(open(TRAIN_YML))["model"]
+    if args.knn:
+        cfg["knn"] = args.knn
+    atoms_range = tuple(int(x) for x in args.atoms.split(",")) if args.atoms else None
     model = ScorePosNet3D(cfg, 15)
     sdn = synth.synthetic_state_dict(cfg, seed=7)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
     model = model.to(dev)
     steps, warm = min(args.steps, CHAIN_STEPS), max(0, min(args.warmup, CHAIN_STEPS))
 
-    bb = synth.synthetic_batch(args.batch, seed=2021 + rank)     # every rank owns a different batch
+    bb = synth.synthetic_batch(args.batch, seed=2021 + rank, atoms_range=atoms_range)     # every rank owns a different batch
     n_atoms = len(bb["batch"])
     runner = ChainRunner(model, n_atoms, args.batch, max(steps, warm, 1), keep_traj=not args.no_traj, device=dev)
     runner.load_batch(bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"])
@@ -140,6 +148,7 @@ def main():
         gather_molecules(runner.out_pos, runner.out_v, counts)
     barrier()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -151,17 +160,28 @@ def main():
         total_atoms = n_atoms
     sec_per_step = elapsed / steps
     value = args.batch * world / (CHAIN_STEPS * sec_per_step)
+    rank_ms = None
+    if dist is not None:       # per-rank step time (the spread shows stragglers; `value` uses the max)
+        mine = torch.tensor([local_elapsed / steps * 1e3], dtype=torch.float64, device=dev)
+        allr = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        rank_ms = [round(float(x), 4) for x in allr.cpu()]
 
     out = {
         "metric": "molecules/sec (1000-step DDPM sample, batch 256)", "value": round(value, 3),
         "unit": "molecules/s", "n_gpus": world, "steps": steps, "warmup": warm,
         "ms_per_step": round(sec_per_step * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: batch 256 MOSES-prior molecules (9-27 atoms) per GPU, "
-                               "1000-step chain, fp32, k=8, synthetic shapes + hash-filled weights",
+        "config": {"workload": (("BASELINE configs[1]: batch 256" if args.batch == 256 else
+                                 ("BASELINE configs[2]/[3] size: batch 1024" if args.batch == 1024 else f"batch {args.batch}")) +
+                                (f" molecules of {atoms_range[0]}-{atoms_range[1]} atoms" if atoms_range else " MOSES-prior molecules (9-27 atoms)") +
+                                f" per GPU, 1000-step chain, fp32 results, k={cfg['knn']}, synthetic shapes + hash-filled weights"),
                    "batch_per_gpu": args.batch, "atoms_per_gpu": n_atoms, "total_atoms": total_atoms,
                    "noise": "device Philox", "trajectories": "kept in HBM" if not args.no_traj else "off",
-                   "launch": "hipGraph replay" if use_graph else "eager", "parallelism": f"dp{world} (whole batches per rank)"},
+                   "launch": "hipGraph replay" if use_graph else "eager", "parallelism": f"dp{world} (whole batches per rank)",
+                   "ranks_seen": (dist.get_world_size() if dist is not None else 1), "ms_per_step_by_rank": rank_ms,
+                   "matrix_products": "edge MLPs: two-piece f16 operands (22 bits), fp32 accumulate; node MLPs: exactly split "
+                                      "bf16 operands (24 bits), fp32 accumulate; everything else fp32"},
     }
 
     log(f"timed region done: {elapsed:.3f} s, {value:.2f} molecules/s")
@@ -182,25 +202,37 @@ def main():
                       "node_pre": 16 * HH * n_atoms}            # 8H x H paired products (the first launch does 4H)
         flops = per_launch.get(dom, 0.0)
         ach = flops / avg_s / 1e12 if flops else 0.0
-        traffic = None                                          # HBM bytes per launch from the committed PMC passes
+        # HBM bytes per launch of that kernel from the committed PMC passes of the same workload (rocprofv3 cannot run
+        # inside this process); null when no committed pass matches the batch size
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "pmc_traffic.json")))
-            if args.batch == 256:
-                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+            name = "pmc_traffic.json" if args.batch == 256 else f"pmc_traffic_b{args.batch}.json"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PROFILE_DIR, name)))
+            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_src = f"profiles/{PROFILE_DIR}/{name} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         except Exception:
-            traffic = None
+            pass
+        # matrix instructions the dominant kernel really issues (f16 or bf16 piece products), against the 2.5 PFLOP/s peak
+        pieces = {"edge_x2h": 3 * 2 * (2 * HH + 2 * 32 * dm.H) * dm.k * n_atoms,
+                  "edge_h2x": 3 * 2 * ((HH + 32 * dm.H) + (16 * dm.H + 32 * dm.H)) * dm.k * n_atoms,
+                  "node_chain": 6 * 14 * HH * n_atoms, "node_pre": 6 * 16 * HH * n_atoms}.get(dom)
+        step_exec = f_exec_total * n_atoms / sec_per_step / 1e12
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01_final/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
+            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "hbm_frac": (round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+            "matrix_pipe_frac": (round(pieces / avg_s / 1e12 / F16_MFMA_PEAK_TFLOPS, 4) if pieces else None),
+            "step_frac": round(step_exec / FP32_MFMA_PEAK_TFLOPS, 4),
             "flops_per_launch_executed": flops, "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_n,
             "share_of_step": round(dom_ms / tot_ms, 3),
-            "note": "achieved/peak are fp32 FLOPs of the kernel's algorithm against the dense fp32 MFMA peak; the edge kernels "
-                    "run both Linears of their MLPs as six exact bf16 piece products on the bf16 matrix cores (fp32-level accuracy), "
-                    "see matrix_pipe",
-            "matrix_pipe": ({"executed_bf16_tflops": round(6 * 2 * (2 * HH + 2 * 32 * dm.H) * dm.k * n_atoms / avg_s / 1e12, 1), "bf16_dense_peak": 2500.0}
-                            if dom == "edge_x2h" else None),
-            "step_tflops_executed": round(f_exec_total * n_atoms / sec_per_step / 1e12, 3),
+            "timing": "begin/end timestamps of the kernel dispatches (hipExtLaunchKernelGGL start/stop events), eager pass "
+                      f"of {max(1, args.profile_steps)} steps right after the timed region; rocprofv3 --kernel-trace --stats of the "
+                      f"same command: profiles/{PROFILE_DIR}/kernel_stats.csv",
+            "note": "achieved/peak: fp32 FLOPs of the kernel's algorithm (factorised first Linears) against the dense fp32 MFMA peak. "
+                    "The step is latency-bound (about 44 dependent launches of 5-20 us on 5.5k atoms), not bound by either roof: "
+                    "hbm_frac = PMC HBM bytes per launch / launch time / 8 TB/s, matrix_pipe_frac = f16/bf16 piece-product FLOPs "
+                    "actually issued / 2.5 PFLOP/s, step_frac = executed fp32 FLOPs of the whole step / step time / fp32 peak",
+            "step_tflops_executed": round(step_exec, 3),
             "step_tflops_ref_equiv": round(reference_flops_per_atom_step(dm.k, dm.L) * n_atoms / sec_per_step / 1e12, 3),
             "breakdown_ms_per_step": {k: round(v[0] / max(1, args.profile_steps), 4) for k, v in prof.items()},
         }
@@ -212,7 +244,7 @@ def main():
                 mj = ScorePosNet3D(cfg, 15)
                 mj.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
                 mj = mj.to(dev)
-                bj = synth.synthetic_batch(args.batch, seed=3021 + j)
+                bj = synth.synthetic_batch(args.batch, seed=3021 + j, atoms_range=atoms_range)
                 rj = ChainRunner(mj, len(bj["batch"]), args.batch, max(steps, warm, 1), keep_traj=not args.no_traj, device=dev)
                 rj.load_batch(bj["init_pos"], bj["init_v"], bj["batch"], bj["shape"])
                 runners.append(rj)
@@ -243,6 +275,7 @@ def main():
             log(f"CPU oracle baseline: {args.cpu_steps} steps")
             dt, cores = cpu_baseline(cfg, bb, args.cpu_steps)
             out["cpu_baseline"] = {"value": round(args.batch / (CHAIN_STEPS * dt), 4), "unit": "molecules/s", "cores": cores,
+                                   "os_cpu_count": os.cpu_count(), "cpu_affinity": len(os.sched_getaffinity(0)),
                                    "kind": "port", "sample": f"{args.cpu_steps} reverse steps of the same B={args.batch} batch "
                                    f"({dt:.3f} s/step, torch-CPU oracle), extrapolated to 1000 steps"}
         print(json.dumps(out), flush=True)

@@ -1033,7 +1033,9 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
             if (capture(1, &c->gexec)) return 1;
             c->gkey = key;
         }
-        if (num_steps >= kGraphUnroll && !c->gexec_u && capture(kGraphUnroll, &c->gexec_u)) return 1;
+        // both executables are built at the first capture, whatever this chain's length: a short warm-up chain then leaves
+        // nothing to capture inside a later, timed chain
+        if (!c->gexec_u && capture(kGraphUnroll, &c->gexec_u)) return 1;
         int st = 0;
         for (; st + kGraphUnroll <= num_steps; st += kGraphUnroll) HIPCHK(hipGraphLaunch(c->gexec_u, s));
         for (; st < num_steps; ++st) HIPCHK(hipGraphLaunch(c->gexec, s));

@@ -228,7 +228,7 @@ class ScorePosNet3D(nn.Module):
             if tuple(eps.shape) != (num_steps, n, 3) or tuple(u.shape) != (num_steps, n, cc):
                 raise ValueError("noise must be (eps (S,N,3), u (S,N,C))")
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
         tr = _lib.Traj()
         bufs = {}
         if return_traj:
@@ -316,8 +316,8 @@ def log_sample_categorical(logits, *, u=None, seed=None):
     n, c = lg.shape
     if u is not None:
         u = _check_device_tensor("u", u, torch.float32)
-    if seed is None:
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    if seed is None:     # host-fed uniforms must not disturb the host generator (the driver's seed-only parity mode)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if u is None else 0
     out = torch.empty((n,), dtype=torch.int64, device=lg.device)
     with torch.cuda.device(lg.device):
         rc = _lib.load().shapemol_log_sample_categorical(None, _ptr(lg), _ptr(u), n, c, C.c_uint64(seed), _ptr(out),

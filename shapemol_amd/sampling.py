@@ -93,7 +93,7 @@ def _traj_to_host(r, name):
 def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device="cuda:0", num_steps=None,
                             pos_only=False, center_pos_mode="none", sample_func=None, threshold_type=None,
                             threshold_args=None, sample_num_atoms="prior", bounds=None, ref_num_atoms=None,
-                            ref_atom_feature=None, guide_stren=0, seed=None, use_graph=True):
+                            ref_atom_feature=None, guide_stren=0, seed=None, use_graph=True, host_rng=False):
     """``sample_diffusion_ligand`` of the reference for one shape condition.
 
     shape_emb        (32, 3) latent of the condition (``data.shape_emb``); repeated per molecule of a batch.
@@ -101,12 +101,25 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
     ref_atom_feature (ref_num_atoms,) int64, needed for ``pos_only`` (atom types are then kept, ``:84-86``).
     bounds           accepted and ignored, like every caller of the reference's ``sample_diffusion`` with guidance off.
     seed             seed of the device noise of the chains (None: drawn from torch's CPU generator per batch).
+    host_rng         True: every random number comes from torch's CPU generator (and numpy's, for the atom counts) in the
+                     order the reference driver consumes them when it runs on the CPU -- ``np.random.choice`` (``:34``),
+                     ``torch.randn(N, 3)`` (``:82``), ``rand_like(N, C)`` for the initial types (``:93`` ->
+                     ``molopt_score_model.py:99``), then per reverse step ``randn_like(N, 3)`` (``molopt_score_model.py:662``)
+                     and ``rand_like(N, C)`` (``:99``) -- and is fed to the device chain: ``np.random.seed(s);
+                     torch.manual_seed(s)`` then reproduces the reference's CPU run from the seeds alone.  Default False:
+                     the chain's noise is generated on the device (Philox), as the reference's own CUDA run draws on the GPU.
+    shape_emb        may also be (n_data, 32, 3), one condition per molecule of a single batch (fixtures).
 
     Returns the reference's 9-tuple: ``(pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj,
     time_list, pred_pos_cond_traj, pred_v_cond_traj)``; positions are float64 host arrays, as there.
     """
     dev = torch.device(device)
-    shape_emb = torch.as_tensor(shape_emb, dtype=torch.float32).reshape(1, -1, 3)
+    shape_emb = torch.as_tensor(shape_emb, dtype=torch.float32)
+    per_mol_shapes = shape_emb.dim() == 3 and shape_emb.shape[0] > 1
+    if per_mol_shapes and (shape_emb.shape[0] != num_samples or num_samples > batch_size):
+        raise ValueError("per-molecule shape conditions need num_samples == shape_emb.shape[0] <= batch_size")
+    if not per_mol_shapes:
+        shape_emb = shape_emb.reshape(1, -1, 3)
     all_pred_pos, all_pred_v = [], []
     all_pred_pos_traj, all_pred_v_traj = [], []
     all_pred_pos_cond_traj, all_pred_v_cond_traj = [], []
@@ -135,13 +148,27 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
             if getattr(model, "v_mode", "categorical") == "gaussian":
                 raise NotImplementedError("v_mode 'gaussian' is not part of the accelerated path")
             uniform_logits = torch.zeros(len(batch_ligand), model.num_classes, device=dev)
-            init_ligand_v = log_sample_categorical(uniform_logits)
+            if host_rng:
+                init_ligand_v = log_sample_categorical(uniform_logits, u=torch.rand(all_ligand_atoms, model.num_classes).to(dev))
+            else:
+                init_ligand_v = log_sample_categorical(uniform_logits)
+        noise_kw = {}
+        if host_rng:
+            if not getattr(model, "_accelerated", False):
+                raise ValueError("host_rng feeds recorded draws to the device chain: it needs the accelerated model")
+            n_steps = num_steps if num_steps is not None else model.num_timesteps
+            eps = torch.empty(n_steps, all_ligand_atoms, 3)
+            uu = torch.empty(n_steps, all_ligand_atoms, model.num_classes)
+            for s_ in range(n_steps):                    # one reverse step at a time: the two streams interleave
+                eps[s_] = torch.randn(all_ligand_atoms, 3)
+                uu[s_] = torch.rand(all_ligand_atoms, model.num_classes)
+            noise_kw["noise"] = (eps.to(dev), uu.to(dev))
         r = model.sample_diffusion(
             init_ligand_pos=init_ligand_pos, init_ligand_v=init_ligand_v, batch_ligand=batch_ligand,
-            ligand_shape=shape_emb.repeat(n_data, 1, 1).to(dev).reshape(n_data, -1),
+            ligand_shape=(shape_emb if per_mol_shapes else shape_emb.repeat(n_data, 1, 1)).to(dev).reshape(n_data, -1),
             threshold_type=threshold_type, threshold_args=threshold_args, num_steps=num_steps,
             center_pos_mode=center_pos_mode, guide_stren=guide_stren, bounds=bounds,
-            seed=None if seed is None else int(seed) + i, use_graph=use_graph,
+            seed=None if seed is None else int(seed) + i, use_graph=use_graph, **noise_kw,
             **({"_reuse_host_buffers": "device"} if getattr(model, "_accelerated", False) else {}))
         cum = np.cumsum([0] + ligand_num_atoms)
         pos = r["pos"].cpu().numpy().astype(np.float64)

@@ -163,3 +163,30 @@ def test_driver_atom_count_prior_window():
     assert a == f(50) and set(a) <= {10, 11, 12, 20} and len(a) == 50
     with pytest.raises(ValueError):
         atom_num_sampler(dists, voxel_shape=5000)
+
+
+def test_pack_result_is_what_the_reference_evaluation_reads(tmp_path):
+    """The result dict is torch.save'd by the reference driver (scripts/sample_diffusion.py:279-299) and consumed by
+    scripts/evaluate_diffusion_sim.py:121-135: r['pred_ligand_pos_traj'][k][eval_step] -> (n_k, 3) float64 positions,
+    r['pred_ligand_v_traj'][k][eval_step] -> (n_k,) integer atom-type indices, one entry per sample."""
+    import torch
+    from shapemol_amd.sampling import pack_result, unbatch
+    counts, S = [3, 5], 4
+    cum = np.cumsum([0] + counts)
+    rs = np.random.RandomState(0)
+    pos_traj = unbatch(rs.randn(S, 8, 3), cum, np.float64)
+    v_traj = unbatch(rs.randint(0, 15, (S, 8)).astype(np.int64), cum)
+    outputs = ([p[-1] for p in pos_traj], [v[-1] for v in v_traj], pos_traj, v_traj, [], [], [0.1], pos_traj, unbatch(rs.randn(S, 8, 15).astype(np.float32), cum))
+    res = pack_result({"id": 7}, outputs)
+    assert list(res) == ["data", "pred_ligand_pos", "pred_ligand_v", "pred_ligand_pos_traj", "pred_ligand_v_traj", "time",
+                         "pred_ligand_pos_cond_traj", "pred_ligand_v_cond_traj"]          # the reference's keys, in its order
+    path = tmp_path / "result_0.pt"
+    torch.save(res, path)
+    r = torch.load(path, weights_only=False)
+    all_pos, all_v = r["pred_ligand_pos_traj"], r["pred_ligand_v_traj"]
+    assert len(all_pos) == len(all_v) == len(counts)
+    for k, (pp, vv) in enumerate(zip(all_pos, all_v)):                                    # the consumer's loop, eval_step = -1
+        p_last, v_last = pp[-1], vv[-1]
+        assert p_last.shape == (counts[k], 3) and p_last.dtype == np.float64
+        assert v_last.shape == (counts[k],) and np.issubdtype(v_last.dtype, np.integer)
+        assert np.array_equal(p_last, r["pred_ligand_pos"][k]) and np.array_equal(v_last, r["pred_ligand_v"][k])
