@@ -440,6 +440,7 @@ struct shapemol_ctx {
     const float *last_h = nullptr, *last_x = nullptr;
     // options
     int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 3, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
+    int edge_tiles = 2;         // multi-job launches of the f16 edge kernels: 2 = two tiles per wave-job (8 waves), 1 = one tile (<= 12 waves)
     float hid_max = 0.f;        // bound of the edge MLPs' hidden activations (LayerNorm outputs): must fit fp16 for edge_bf16 = 3
     int num_cu = 256;
     int first_step = 0;         // option "first_step": the next chains start at reverse step first_step (t = T-1-first_step)
@@ -543,7 +544,11 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
-    if (KP == 8) { SETATTR(8) SETATTR2(8) SETATTR3(8) SETATTR4(8) } else if (KP == 16) { SETATTR(16) SETATTR2(16) SETATTR3(16) SETATTR4(16) } else { SETATTR(32) }
+#define SETATTR5(K)                                                                                                   \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16x2_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16x2_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + 512 * 16));
+    if (KP == 8) { SETATTR(8) SETATTR2(8) SETATTR3(8) SETATTR4(8) SETATTR5(8) } else if (KP == 16) { SETATTR(16) SETATTR2(16) SETATTR3(16) SETATTR4(16) SETATTR5(16) } else { SETATTR(32) SETATTR5(32) }
+#undef SETATTR5
 #undef SETATTR4
 #undef SETATTR2
 #undef SETATTR3
@@ -605,20 +610,34 @@ int launch_fused(shapemol_ctx *c, hipStream_t s, const EdgeFusedArgs &a) {
 
 template <int H, bool H2X>
 int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
-    const int KP = c->KP, apj = 16 / KP;
-    const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
-    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
-    const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
-                       + (H2X ? (size_t)vn_red_doubles(waves, H / 8) * 8 + (size_t)waves * apj * 48 * 4 : 0);
+    const int KP = c->KP;
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
-    const bool one = njobs <= grid * waves;      // every wave has at most one job: straight-line instantiation
-    if (KP == 8) {
-        if (one) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
-        else LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
-    } else {
-        if (one) LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
-        else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+    if (KP <= 16) {
+        const int apj = 16 / KP;
+        const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
+        const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
+        const bool one = njobs <= grid * waves;      // every wave has at most one job: straight-line instantiation
+        if (one || c->edge_tiles != 2) {
+            const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
+                               + (H2X ? (size_t)vn_red_doubles(waves, H / 8) * 8 + (size_t)waves * apj * 48 * 4 : 0);
+            if (KP == 8) {
+                if (one) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
+                else LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+            } else {
+                if (one) LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
+                else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+            }
+            return 0;
+        }
     }
+    // two tiles per wave-job, eight waves per workgroup: several jobs per wave (large batches) and k > 16
+    const int apj2 = KP == 32 ? 1 : 32 / KP;
+    const int njobs = (a.n_atoms + apj2 - 1) / apj2, waves = 8;
+    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
+    const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float) + (H2X ? 512 * 16 : 0);
+    if (KP == 8) LAUNCH(nm, SMK((edge16x2_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else if (KP == 16) LAUNCH(nm, SMK((edge16x2_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else LAUNCH(nm, SMK((edge16x2_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     return 0;
 }
 
@@ -738,7 +757,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         const DevLayer &Dl = c->dm.layer[l];
         const bool last = (l == nlay - 1), has_next = !last;
         const bool phases = c->edge_bf16 && KP <= 16;
-        const bool f16 = phases && c->edge_bf16 == 3;     // two-piece f16 operands (sm_edge16.h), the default
+        const bool f16 = c->edge_bf16 == 3;     // two-piece f16 operands (sm_edge16.h), the default
         if (f16) {   // x2h attention: both MLP images resident, one barrier
             Edge16Args ea{};
             ea.image_k = c->P(Dl.i16_kx); ea.image_v = c->P(Dl.i16_vx);
@@ -1070,6 +1089,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
         if (value == 3 && c->hid_max > 6.0e4f) return fail("edge_bf16 = 3: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights");
         c->edge_bf16 = (int)value;
     }
+    else if (k == "edge_tiles") { if (value != 1 && value != 2) return fail("edge_tiles must be 1 or 2"); c->edge_tiles = (int)value; }
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "chain_bf16") c->chain_bf16 = (int)value;
     else if (k == "vn_fuse") c->vn_fuse = (int)value;

@@ -375,3 +375,296 @@ edge16_kernel(Edge16Args a) {
         }
     }
 }
+
+// -------------------------------------------------------------------------------------------------------------------
+// Throughput instantiation: TWO 16-column tiles per wave-job, several jobs per wave, two waves per SIMD (8 per
+// workgroup, 256 VGPRs).  Used when the waves have more than one job each (batches beyond ~6k atoms) and for k > 16:
+//   KP = 8 / 16 : the two tiles are independent (4 / 2 centre atoms per job), softmax inside each tile as above;
+//   KP = 32     : one centre atom per job, its 32 neighbour slots span both tiles; max and sum of the softmax and the
+//                 weighted neighbour sums are combined across the two tiles in registers (same wave).
+// Every A fragment read from LDS feeds both tiles (half the LDS traffic per matrix instruction), and the next job's
+// key rows are requested before the value MLP's second Linear of the current job.
+// -------------------------------------------------------------------------------------------------------------------
+template <int NT, int NT2>
+SM_DEV void tile2_f16x3(const unsigned *w2, int t2, const u32x4 (&bh0)[NT / 2], const u32x4 (&bl0)[NT / 2],
+                        const u32x4 (&bh1)[NT / 2], const u32x4 (&bl1)[NT / 2], f32x4 &c0, f32x4 &c1, int lane) {
+    constexpr int NB = NT / 2;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const u32x4 ah = *reinterpret_cast<const u32x4 *>(w2 + (((0 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+        const u32x4 al = *reinterpret_cast<const u32x4 *>(w2 + (((1 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+        c0 = mfma_f16(al, bh0[b], c0); c1 = mfma_f16(al, bh1[b], c1);
+        c0 = mfma_f16(ah, bl0[b], c0); c1 = mfma_f16(ah, bl1[b], c1);
+        c0 = mfma_f16(ah, bh0[b], c0); c1 = mfma_f16(ah, bh1[b], c1);
+    }
+}
+
+template <int H, int KP, bool H2X>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+edge16x2_kernel(Edge16Args a) {
+    static_assert(KP == 8 || KP == 16 || KP == 32, "two tiles per job");
+    constexpr int NT = H / 16;
+    constexpr int NT2V = H2X ? 1 : NT;
+    using IMK = EdgeImage16<H, NT>;
+    using IMV = EdgeImage16<H, NT2V>;
+    constexpr int V_BASE = IMK::TOTAL;
+    constexpr bool WIDE = KP == 32;                               // one atom across both tiles
+    constexpr int SEGW = KP >= 16 ? 16 : KP;                      // lanes of one atom inside a tile
+    constexpr int APT = 16 / SEGW;                                // atoms per tile
+    constexpr int APJ = WIDE ? 1 : 2 * APT;                       // atoms per job
+    constexpr int HD = H / 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    float cen[5];
+    rbf_centres(g, cen);
+    const int njobs = (a.n_atoms + APJ - 1) / APJ;
+    const int jstride = gridDim.x * nwave;
+    const int job0 = blockIdx.x * nwave + wave;
+
+    int atom[2], jn[2], edge[2];
+    bool atom_ok[2], ok[2];
+    float xi[2][3], xj[2][3], wgt[2];
+    float4 ga[2][NT], gb[2][NT];
+
+    auto locate = [&](int jb, int tl) {
+        const int atom_raw = WIDE ? jb : jb * APJ + tl * APT + n / SEGW;
+        atom_ok[tl] = atom_raw < a.n_atoms;
+        atom[tl] = atom_ok[tl] ? atom_raw : a.n_atoms - 1;
+        edge[tl] = atom[tl] * KP + (WIDE ? 16 * tl + n : n % SEGW);
+        const int jraw = a.nbr[edge[tl]];
+        ok[tl] = atom_ok[tl] && jraw >= 0;
+        jn[tl] = ok[tl] ? jraw : atom[tl];
+    };
+    auto request = [&](int tl) {      // key-MLP rows of one tile
+        const float *pi = a.pre + (size_t)atom[tl] * a.ld_pre, *pj = a.pre + (size_t)jn[tl] * a.ld_pre + H;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { ga[tl][t] = ldg4(pi + 16 * t + 4 * g); gb[tl][t] = ldg4(pj + 16 * t + 4 * g); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { xi[tl][k] = a.x[atom[tl] * 3 + k]; xj[tl][k] = a.x[jn[tl] * 3 + k]; }
+        wgt[tl] = a.ew[edge[tl]];
+    };
+    auto request_v = [&]() {          // value-MLP rows (the key rows have been consumed)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const float *pi = a.pre + (size_t)atom[tl] * a.ld_pre + 2 * H, *pj = a.pre + (size_t)jn[tl] * a.ld_pre + 3 * H;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { ga[tl][t] = ldg4(pi + 16 * t + 4 * g); gb[tl][t] = ldg4(pj + 16 * t + 4 * g); }
+        }
+    };
+    auto hidden = [&](const float *img, auto im_tag, int tl, u32x4 rh, u32x4 rl, u32x4 (&bh)[NT / 2], u32x4 (&bl)[NT / 2]) {
+        using IM = decltype(im_tag);
+        float hid[NT * 4];
+        {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = f32x4{ga[tl][t].x + gb[tl][t].x, ga[tl][t].y + gb[tl][t].y, ga[tl][t].z + gb[tl][t].z, ga[tl][t].w + gb[tl][t].w};
+            first_linear16<NT>(reinterpret_cast<const unsigned *>(img) + IM::O_W1, rh, rl, acc, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
+                hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
+            }
+        }
+        ln_relu_dlayout<NT>(hid, img + IM::O_G, img + IM::O_B, g);
+        split_act16<NT>(hid, bh, bl);
+    };
+
+    dma_to_lds(lds, a.image_k, IMK::TOTAL / 4, wave, nwave, lane);
+    dma_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, wave, nwave, lane);
+    if (job0 < njobs) { locate(job0, 0); locate(job0, 1); request(0); }
+    __syncthreads();
+
+    const float *imk = lds, *imv = lds + V_BASE;
+    const unsigned *w2k = reinterpret_cast<const unsigned *>(imk) + IMK::O_W2;
+    const unsigned *w2v = reinterpret_cast<const unsigned *>(imv) + IMV::O_W2;
+    double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);
+
+    for (int job = job0; job < njobs; job += jstride) {
+        asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
+        request(1);                      // tile 1's key rows fly under tile 0's hidden layer (tile 0's were requested a job ahead)
+        float rel[2][3];
+        u32x4 rh[2], rl[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rel[tl][k] = xi[tl][k] - xj[tl][k];
+            float rb[5];
+            rbf_dlayout(sqrtf(rel[tl][0] * rel[tl][0] + rel[tl][1] * rel[tl][1] + rel[tl][2] * rel[tl][2]), cen, rb);
+            unsigned h, l;
+            rh[tl] = u32x4{0u, 0u, 0u, 0u}; rl[tl] = u32x4{0u, 0u, 0u, 0u};
+            split2_pair(rb[0], rb[1], h, l); rh[tl][0] = h; rl[tl][0] = l;
+            split2_pair(rb[2], rb[3], h, l); rh[tl][1] = h; rl[tl][1] = l;
+            split2_pair(rb[4], 0.f, h, l); rh[tl][2] = h; rl[tl][2] = l;
+        }
+        const int cur_atom[2] = {atom[0], atom[1]};
+        const bool cur_ok[2] = {ok[0], ok[1]}, cur_atom_ok[2] = {atom_ok[0], atom_ok[1]};
+        const float w[2] = {ok[0] ? wgt[0] : 0.f, ok[1] ? wgt[1] : 0.f};
+        // ---- key phase -------------------------------------------------------------------------------------------------
+        float alpha[2][NT / 2];
+        {
+            u32x4 kh[2][NT / 2], kl[2][NT / 2];
+            hidden(imk, IMK{}, 0, rh[0], rl[0], kh[0], kl[0]);
+            hidden(imk, IMK{}, 1, rh[1], rl[1], kh[1], kl[1]);
+            const float *q0 = a.q + (size_t)cur_atom[0] * H + 4 * g, *q1 = a.q + (size_t)cur_atom[1] * H + 4 * g;
+#pragma unroll
+            for (int t = 0; t < NT / 2; ++t) {
+                const float4 qa0 = ldg4(q0 + 16 * t), qb0 = ldg4(q0 + 16 * (t + NT / 2));
+                const float4 qa1 = ldg4(q1 + 16 * t), qb1 = ldg4(q1 + 16 * (t + NT / 2));
+                f32x4 ka0 = {0.f, 0.f, 0.f, 0.f}, ka1 = ka0, kb0 = ka0, kb1 = ka0;
+                tile2_f16x3<NT, NT>(w2k, t, kh[0], kl[0], kh[1], kl[1], ka0, ka1, lane);
+                tile2_f16x3<NT, NT>(w2k, t + NT / 2, kh[0], kl[0], kh[1], kl[1], kb0, kb1, lane);
+                if constexpr (!WIDE) {
+                    alpha[0][t] = attention_weight_pair<NT, SEGW>(qa0, qb0, ka0, kb0, cur_ok[0]);
+                    alpha[1][t] = attention_weight_pair<NT, SEGW>(qa1, qb1, ka1, kb1, cur_ok[1]);
+                } else {
+                    // logits of both tiles (same head pairing as attention_weight_pair), softmax over the 32 slots of the atom
+                    float p[2];
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) {
+                        const float4 qa = tl ? qa1 : qa0, qb = tl ? qb1 : qb0;
+                        const f32x4 ka = tl ? ka1 : ka0, kb = tl ? kb1 : kb0;
+                        float pa = qa.x * ka[0] + qa.y * ka[1] + qa.z * ka[2] + qa.w * ka[3];
+                        float pb = qb.x * kb[0] + qb.y * kb[1] + qb.z * kb[2] + qb.w * kb[3];
+                        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(pa), "+v"(pb));
+                        p[tl] = cur_ok[tl] ? (pa + pb) * 0.35355339059327373f : -INFINITY;
+                    }
+                    const float mx = fmaxf(seg_max<16>(p[0]), seg_max<16>(p[1]));
+                    const float e0 = cur_ok[0] ? fast_exp(p[0] - mx) : 0.f, e1 = cur_ok[1] ? fast_exp(p[1] - mx) : 0.f;
+                    const float s = seg_sum<16>(e0) + seg_sum<16>(e1);
+                    const float inv = s > 0.f ? __builtin_amdgcn_rcpf(s) : 0.f;
+                    alpha[0][t] = e0 * inv; alpha[1][t] = e1 * inv;
+                }
+            }
+        }
+        // ---- value phase (its rows are requested here: with two tiles in flight the register file has no room for them
+        //      during the key MLP's second Linear; the SIMD's other wave covers the latency) ----------------------------
+        {
+            request_v();
+            u32x4 vh[2][NT / 2], vl[2][NT / 2];
+            hidden(imv, IMV{}, 0, rh[0], rl[0], vh[0], vl[0]);
+            hidden(imv, IMV{}, 1, rh[1], rl[1], vh[1], vl[1]);
+            if (job + jstride < njobs) { locate(job + jstride, 0); locate(job + jstride, 1); request(0); }   // next job: tile 0's key rows fly under this second Linear
+            const float *b2 = imv + IMV::O_B2;
+            const bool st0 = cur_atom_ok[0] && (n % SEGW) == 0, st1 = !WIDE && cur_atom_ok[1] && (n % SEGW) == 0;
+            if constexpr (!H2X) {
+                float al[2][NT];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int t = 0; t < NT / 2; ++t) {
+                        float lo = alpha[tl][t], hi = alpha[tl][t];
+                        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                        al[tl][t] = lo * w[tl]; al[tl][t + NT / 2] = hi * w[tl];
+                    }
+                float *op0 = a.out + (size_t)cur_atom[0] * H, *op1 = a.out + (size_t)cur_atom[1] * H;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                    tile2_f16x3<NT, NT>(w2v, t, vh[0], vl[0], vh[1], vl[1], v0, v1, lane);
+                    const float4 bb = ldg4(b2 + 16 * t + 4 * g);
+                    float o0[4], o1[4];
+                    float sw0 = seg_sum<SEGW>(al[0][t]), sw1 = seg_sum<SEGW>(al[1][t]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { o0[r] = seg_sum<SEGW>(al[0][t] * v0[r]); o1[r] = seg_sum<SEGW>(al[1][t] * v1[r]); }
+                    if constexpr (WIDE) {
+                        sw0 += sw1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o0[r] += o1[r];
+                    }
+                    if (st0) stg4(op0 + 16 * t + 4 * g, float4{o0[0] + sw0 * bb.x, o0[1] + sw0 * bb.y, o0[2] + sw0 * bb.z, o0[3] + sw0 * bb.w});
+                    if (st1) stg4(op1 + 16 * t + 4 * g, float4{o1[0] + sw1 * bb.x, o1[1] + sw1 * bb.y, o1[2] + sw1 * bb.z, o1[3] + sw1 * bb.w});
+                }
+            } else {
+                const float4 bb = ldg4(b2 + 4 * g);
+                f32x4 va0 = {bb.x, bb.y, bb.z, bb.w}, va1 = va0;
+                tile2_f16x3<NT, 1>(w2v, 0, vh[0], vl[0], vh[1], vl[1], va0, va1, lane);
+                float o[2][12];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float av = r < NT / 2 ? alpha[tl][r % (NT / 2)] * w[tl] * (tl ? va1[r] : va0[r]) : 0.f;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) o[tl][3 * r + k] = seg_sum<SEGW>(av * rel[tl][k]);
+                    }
+                if constexpr (WIDE) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) o[0][i] += o[1][i];
+                }
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+                    if (tl == 0 ? st0 : st1) {
+                        float *op = a.out + (size_t)cur_atom[tl] * 48 + 12 * g;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            stg4(op + 4 * i, float4{o[tl][4 * i], o[tl][4 * i + 1], o[tl][4 * i + 2], o[tl][4 * i + 3]});
+                    }
+            }
+        }
+    }
+
+    if constexpr (H2X) {
+        if (!a.vn.enable) return;
+        // VN-linear + batch sums of this wave's atoms (see edge16_kernel); the attention rows come back through L2
+        const int v_al = lane >> 4, v_c = lane & 15;
+        const bool v_lane = v_al < APJ && v_c < HD;
+        double v_s1 = 0.0, v_s2 = 0.0;
+        __syncthreads();                             // drain this workgroup's stores first
+        for (int jb = job0; jb < njobs; jb += jstride) {
+            const int va = jb * APJ + v_al;
+            if (v_lane && va < a.n_atoms) {
+                float orow[48];
+                const float *ov = a.out + (size_t)va * 48;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const float4 t = ldg4(ov + 4 * i);
+                    orow[4 * i] = t.x; orow[4 * i + 1] = t.y; orow[4 * i + 2] = t.z; orow[4 * i + 3] = t.w;
+                }
+                float wf[16], wd[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 t = ldg4(a.vn.wf_o + v_c * 16 + 4 * i), u = ldg4(a.vn.wd_o + v_c * 16 + 4 * i);
+                    wf[4 * i] = t.x; wf[4 * i + 1] = t.y; wf[4 * i + 2] = t.z; wf[4 * i + 3] = t.w;
+                    wd[4 * i] = u.x; wd[4 * i + 1] = u.y; wd[4 * i + 2] = u.z; wd[4 * i + 3] = u.w;
+                }
+                const float *psf = a.vn.ps + ((size_t)a.vn.mol_of[va] * 2 * HD + v_c) * 3;
+                const float *psd = psf + HD * 3;
+                const float wfx = a.vn.wf_x[v_c], wdx = a.vn.wd_x[v_c];
+                float p[3], d[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float xk = a.x[va * 3 + k];
+                    float pp = wfx * xk, dd = wdx * xk;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        pp += wf[r] * orow[r * 3 + k];
+                        dd += wd[r] * orow[r * 3 + k];
+                    }
+                    p[k] = pp + psf[k];
+                    d[k] = dd + psd[k];
+                }
+                float *out = a.vn.pd + ((size_t)va * HD + v_c) * 6;
+                out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
+                const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
+                v_s1 += (double)nrm;
+                v_s2 += (double)nrm * (double)nrm;
+            }
+        }
+        vn_red[threadIdx.x * 2] = v_s1; vn_red[threadIdx.x * 2 + 1] = v_s2;      // [wave][lane]
+        __syncthreads();
+        if (threadIdx.x < HD) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int w = 0; w < nwave; ++w)
+                for (int al = 0; al < APJ; ++al) {
+                    s1 += vn_red[(w * 64 + al * 16 + threadIdx.x) * 2];
+                    s2 += vn_red[(w * 64 + al * 16 + threadIdx.x) * 2 + 1];
+                }
+            double *acc = a.vn.acc + (size_t)(blockIdx.x % kVnReplicas) * 2 * HD;
+            atomicAdd(acc + threadIdx.x, s1);
+            atomicAdd(acc + HD + threadIdx.x, s2);
+        }
+    }
+}

@@ -555,3 +555,44 @@ def test_sampling_driver_reproduces_reference_from_seeds():
         assert np.array_equal(v_traj[k], c["v_traj"][:, off[k]:off[k + 1]])
         assert pos[k].dtype == np.float64 and pos_traj[k].shape == (50, counts[k], 3)
     assert maxabs(np.concatenate([x[-1] for x in vt_traj]), c["vt_last"]) < POS_TOL
+
+
+def test_forward_k32_b64_golden():
+    """BASELINE configs[4] analogue: 64 molecules of 40-80 atoms, k = 32, full depth, against the reference."""
+    from util import record
+    f = golden("forward_k32_b64.npz")
+    m = hip_model(seed=9, knn=32)
+    bb = synth.synthetic_batch(64, seed=35, atoms_range=(40, 80))
+    assert np.array_equal(bb["counts"], f["counts"])
+    with torch.no_grad():
+        out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(f["t"], DEV))
+    errs = {k: maxabs(out[k], f[k]) for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v")}
+    record("forward_k32_b64_golden", n_atoms=len(bb["batch"]), **errs)
+    assert max(errs.values()) < FWD_TOL, errs
+
+
+def test_chain_k32_b64_s20_golden():
+    """The same configuration over 20 reverse steps against the reference: atom types exact, coordinates within 1e-4."""
+    from util import record
+    errs = _golden_chain(hip_model(seed=9, knn=32), golden("chain_k32_b64_s20_hash.npz"), atoms_range=(40, 80))
+    record("chain_k32_b64_s20_golden", **errs)
+    assert errs["v_mismatch_end"] == 0 and errs["v_mismatch_snapshots"] == 0, errs
+    assert errs["pos_end"] < POS_TOL and errs["pos_snapshots"] < POS_TOL, errs
+
+
+@pytest.mark.parametrize("tiles", [1, 2])
+def test_forward_b1024_edge_tile_variants(tiles):
+    """Both multi-job instantiations of the f16 edge kernels (one / two 16-column tiles per wave-job) at B = 1024."""
+    m = hip_model()
+    sd, dm, _, _ = oracle_model()
+    bb = synth.synthetic_batch(1024, seed=14, max_atoms=38)
+    t = (synth.hash_u24(1024, 9, 14) % 1000).astype(np.int64)
+    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    try:
+        m.set_option("edge_tiles", tiles)
+        with torch.no_grad():
+            out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
+    finally:
+        m.set_option("edge_tiles", 2)
+    for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+        assert maxabs(out[k], ref[k]) < FWD_TOL, k
