@@ -103,6 +103,20 @@ int shapemol_sample(shapemol_ctx *ctx, const float *d_init_pos, const int64_t *d
                     const shapemol_traj *traj, float *out_pos, int64_t *out_v,
                     int32_t use_graph, void *stream);
 
+/* Point-cloud shape guidance of the following _sample calls (pointcloud_shape_guidance,
+ * models/molopt_score_model.py:699-740; applied to the predicted x0 of every step with t > grad_step, :583-586):
+ * an atom whose three nearest cloud points are on average farther than `radius` is pulled towards their mean by a random
+ * fraction in [0.2, 0.8), up to five times.  h_cloud: HOST (n_points,3) float64 (copied); n_points = 0 switches it off.
+ * d_draws: DEVICE (S,5,N) float64 uniforms, the np.random.random() draw of every (step, iteration, atom) (parity mode;
+ * entries of atoms that are not pulled are ignored), or NULL: Philox(seed of the chain).  Replaces the reference's
+ * per-step D2H + KD-tree + H2D round trip by one kernel inside the step graph. */
+int shapemol_set_guidance(shapemol_ctx *ctx, const double *h_cloud, int64_t n_points, double radius,
+                          int32_t grad_step, const double *d_draws);
+
+/* pointcloud_shape_guidance on its own (models/molopt_score_model.py:699-740): guide d_pos (N,3) f32 in place against the
+ * cloud of shapemol_set_guidance; d_draws DEVICE (5,N) float64 or NULL (Philox(seed)). */
+int shapemol_guide_points(shapemol_ctx *ctx, float *d_pos, int64_t n_points, const double *d_draws, uint64_t seed, void *stream);
+
 /* Input validation happens on the device (no host synchronisation in _score/_sample): an unsorted or
  * out-of-range d_batch, an atom type outside [0, num_classes) or a time step outside [0, num_timesteps)
  * sets a sticky flag (the offending index is clamped, so nothing is read or written out of bounds).

@@ -259,9 +259,11 @@ def posterior_step(sd, dm, pos, v, pred_pos, pred_v, batch, t, eps, u):
 
 
 @torch.no_grad()
-def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, keep_traj=True):
+def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, keep_traj=True, guidance=None):
     """Reverse chain t = T-1 ... T-num_steps with host-fed noise ``noise_fn(step) -> (eps, u)``
-    (numpy or torch arrays; per step eps (N,3) first, then u (N,C), the reference's draw order)."""
+    (numpy or torch arrays; per step eps (N,3) first, then u (N,C), the reference's draw order).
+    guidance = (cloud, radius, grad_step, draws (S,5,N)): point-cloud guidance of the predicted x0 while t > grad_step
+    (/root/reference/models/molopt_score_model.py:583-586)."""
     B = int(batch.max()) + 1
     shape = shape.view(B, -1, 3)
     pos, v = init_pos, init_v
@@ -269,6 +271,9 @@ def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, ke
     for s, i in enumerate(reversed(range(dm.T - num_steps, dm.T))):
         t = torch.full((B,), i, dtype=torch.long)
         pr = score(sd, dm, pos, v, batch, shape, t)
+        if guidance is not None and i > guidance[2]:
+            pr["pred_ligand_pos"] = torch.from_numpy(pointcloud_shape_guidance(guidance[0], guidance[1], pr["pred_ligand_pos"].numpy(),
+                                                                              guidance[3][s]))
         eps, u = noise_fn(s)
         eps, u = torch.as_tensor(eps), torch.as_tensor(u)
         pos, v, log_v0, log_post = posterior_step(sd, dm, pos, v, pr["pred_ligand_pos"], pr["pred_ligand_v"],
@@ -278,6 +283,36 @@ def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, ke
             out["v0_traj"].append(log_v0); out["vt_traj"].append(log_post)
             out["pos_cond_traj"].append(pr["pred_ligand_pos"]); out["v_cond_traj"].append(pr["pred_ligand_v"])
     out["pos"], out["v"] = pos, v
+    return out
+
+
+def pointcloud_shape_guidance(cloud, radius, pred_pos, draws, k=3, ratio=0.2):
+    """Point-cloud shape guidance of a predicted x0 (/root/reference/models/molopt_score_model.py:699-740), restated with a
+    brute-force float64 nearest-point search in place of the sklearn KD-tree and with the uniform draws given per
+    (iteration, atom) (``draws`` (5, N) float64: the value np.random.random() hands the atom in that iteration).
+    pred_pos (N,3) float32 array; returns the guided float32 array."""
+    cloud = np.asarray(cloud, np.float64)
+    out = np.array(pred_pos, np.float32, copy=True)
+
+    def query(x):
+        d2 = ((x[:, None, :].astype(np.float64) - cloud[None, :, :]) ** 2).sum(-1)
+        idx = np.argsort(d2, axis=1, kind="stable")[:, :k]
+        return np.sqrt(np.take_along_axis(d2, idx, 1)), idx
+
+    dists, idxs = query(out)
+    far = np.where(dists.mean(1) > radius)[0]
+    pts, pidx = out[far].astype(np.float64), idxs[far]
+    for j in range(5):
+        if len(far) == 0:
+            break
+        nearest = cloud[pidx].mean(1)
+        scalar = (draws[j, far] * (0.8 - ratio) + ratio)[:, None]
+        pts = pts - scalar * (pts - nearest)
+        dists, idxs = query(pts)
+        inside = dists.mean(1) < radius
+        out[far[inside]] = pts[inside].astype(np.float32)
+        far, pts, pidx = far[~inside], pts[~inside], idxs[~inside]
+    out[far] = pts.astype(np.float32)          # still outside after five pulls: keep the last position (:733-735)
     return out
 
 

@@ -17,7 +17,7 @@ EXPORTS = (
     "shapemol_abi_version", "shapemol_last_error", "shapemol_weight_count", "shapemol_create",
     "shapemol_destroy", "shapemol_reserve", "shapemol_score", "shapemol_sample",
     "shapemol_log_sample_categorical", "shapemol_set_option", "shapemol_debug_read",
-    "shapemol_profile_begin", "shapemol_profile_end", "shapemol_status",
+    "shapemol_profile_begin", "shapemol_profile_end", "shapemol_status", "shapemol_set_guidance", "shapemol_guide_points",
 )
 
 
@@ -79,6 +79,8 @@ def load():
     lib.shapemol_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     lib.shapemol_debug_read.restype = i64
     lib.shapemol_status.argtypes = [vp, vp]
+    lib.shapemol_set_guidance.argtypes = [vp, vp, i64, C.c_double, i32, vp]
+    lib.shapemol_guide_points.argtypes = [vp, vp, i64, vp, u64, vp]
     lib.shapemol_profile_begin.argtypes = [vp]
     lib.shapemol_profile_end.argtypes = [vp, vp, vp, vp, C.c_int]
     if lib.shapemol_abi_version() != ABI_VERSION:

@@ -443,6 +443,8 @@ struct shapemol_ctx {
     int edge_tiles = 2;         // multi-job launches of the f16 edge kernels: 2 = two tiles per wave-job (8 waves), 1 = one tile (<= 12 waves)
     float hid_max = 0.f;        // bound of the edge MLPs' hidden activations (LayerNorm outputs): must fit fp16 for edge_bf16 = 3
     int num_cu = 256;
+    // point-cloud shape guidance (shapemol_set_guidance)
+    double *g_cloud = nullptr; int64_t g_points = 0; double g_radius = 0.0; int g_grad_step = 0; const double *g_draws = nullptr;
     int first_step = 0;         // option "first_step": the next chains start at reverse step first_step (t = T-1-first_step)
     // profiling
     bool prof_on = false;
@@ -452,7 +454,7 @@ struct shapemol_ctx {
     hipGraphExec_t gexec = nullptr, gexec_u = nullptr;     // one step / kGraphUnroll steps
     int64_t n_captures = 0;                                // graph captures so far (debug_read "captures")
     // the captured step depends on the batch geometry only: seed, noise and trajectory pointers live in chain_params
-    struct GraphKey { int64_t N = 0, B = 0; bool operator==(const GraphKey &o) const { return N == o.N && B == o.B; } } gkey{};
+    struct GraphKey { int64_t N = 0, B = 0; int guided = 0; bool operator==(const GraphKey &o) const { return N == o.N && B == o.B && guided == o.guided; } } gkey{};
     void drop_graphs() {      // a replay may still be in flight: drain the device before destroying the executables
         if (!gexec && !gexec_u) return;
         hipDeviceSynchronize();
@@ -974,6 +976,7 @@ void shapemol_destroy(shapemol_ctx *c) {
     for (void *p : c->allocs) hipFree(p);
     hipFree(c->ttab);
     hipFree(c->d_img);
+    if (c->g_cloud) hipFree(c->g_cloud);
     delete c;
 }
 
@@ -1016,7 +1019,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
     LAUNCH("prep", SMK(v_check_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_init_v, (int)N, c->cfg.num_classes, c->status));
     {
         ChainParams cp{};
-        cp.seed = seed; cp.eps = d_eps; cp.u = d_u; cp.step_base = c->first_step;
+        cp.seed = seed; cp.eps = d_eps; cp.u = d_u; cp.step_base = c->first_step; cp.guide_draws = c->g_draws;
         if (traj) { cp.tr_pos = traj->pos_traj; cp.tr_v = traj->v_traj; cp.tr_v0 = traj->v0_traj; cp.tr_vt = traj->vt_traj;
                     cp.tr_pos_cond = traj->pos_cond_traj; cp.tr_v_cond = traj->v_cond_traj; }
         LAUNCH("prep", SMK(set_chain_params_kernel, dim3(1), dim3(1), 0, s, c->chain_params, cp, c->steps));
@@ -1026,11 +1029,15 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
     auto one_step = [&]() -> int {
         if (DISPATCH_H(c, run_score<128>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v),
                        run_score<32>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v))) return 1;
+        if (c->g_points > 0) {     // point-cloud shape guidance of the predicted x0 (steps with t > grad_step)
+            PcGuideArgs ga{c->pred_pos, c->g_cloud, c->chain_params, c->steps + 1, (int)N, (int)c->g_points, t_first, c->g_grad_step, c->g_radius};
+            LAUNCH("pc_guidance", SMK(pc_guidance_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, s, ga));
+        }
         return DISPATCH_H(c, run_ddpm<128>(c, s, N), run_ddpm<32>(c, s, N));
     };
     if (use_graph && !c->prof_on) {
         shapemol_ctx::GraphKey key{};
-        key.N = N; key.B = B;
+        key.N = N; key.B = B; key.guided = c->g_points > 0;
         // two executables: one reverse step, and kGraphUnroll steps back to back (the gap between two graph launches,
         // ~5 us, is then paid once per kGraphUnroll steps); every step reads its index from the device-side counter
         auto capture = [&](int n_steps, hipGraphExec_t *exec) -> int {
@@ -1129,6 +1136,35 @@ int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t
     if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("shapemol_debug_read: copy failed"); return -1; }
     return (int64_t)bytes;
+}
+
+int shapemol_set_guidance(shapemol_ctx *c, const double *h_cloud, int64_t n_points, double radius, int32_t grad_step, const double *d_draws) {
+    if (!c) return fail("shapemol_set_guidance: null ctx");
+    if (n_points < 0 || n_points > (1 << 22) || (n_points > 0 && n_points < 3)) return fail("shapemol_set_guidance: the cloud needs at least 3 points");
+    if (n_points > 0 && (!h_cloud || !(radius > 0.0))) return fail("shapemol_set_guidance: cloud / radius missing");
+    HIPCHK(hipSetDevice(c->device));
+    c->drop_graphs();                            // also drains the device: the old cloud may still be in use
+    if (c->g_cloud) { hipFree(c->g_cloud); c->g_cloud = nullptr; }
+    c->g_points = 0; c->g_draws = nullptr;
+    if (n_points == 0) return 0;
+    HIPCHK(hipMalloc((void **)&c->g_cloud, (size_t)n_points * 3 * sizeof(double)));
+    HIPCHK(hipMemcpy(c->g_cloud, h_cloud, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice));
+    c->g_points = n_points; c->g_radius = radius; c->g_grad_step = grad_step; c->g_draws = d_draws;
+    return 0;
+}
+
+int shapemol_guide_points(shapemol_ctx *c, float *d_pos, int64_t N, const double *d_draws, uint64_t seed, void *stream) {
+    if (!c || !d_pos || N < 1) return fail("shapemol_guide_points: bad argument");
+    if (c->g_points <= 0) return fail("shapemol_guide_points: no cloud set (shapemol_set_guidance)");
+    HIPCHK(hipSetDevice(c->device));
+    if (ensure_workspace(c, std::max<int64_t>(N, 1), 1)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    ChainParams cp{};
+    cp.seed = seed; cp.guide_draws = d_draws; cp.step_base = 0;
+    LAUNCH("prep", SMK(set_chain_params_kernel, dim3(1), dim3(1), 0, s, c->chain_params, cp, c->steps));
+    PcGuideArgs ga{d_pos, c->g_cloud, c->chain_params, nullptr, (int)N, (int)c->g_points, c->g_grad_step + 1, c->g_grad_step, c->g_radius};
+    LAUNCH("pc_guidance", SMK(pc_guidance_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, s, ga));
+    return 0;
 }
 
 int shapemol_status(shapemol_ctx *c, int32_t *flags_out) {

@@ -412,6 +412,7 @@ struct ChainParams {
     unsigned long long seed;
     const float *eps, *u;    // host-fed noise of ALL steps ([S][N][3], [S][N][C]) or nullptr
     float *tr_pos; int64_t *tr_v; float *tr_v0; float *tr_vt; float *tr_pos_cond; float *tr_v_cond;  // trajectories or nullptr
+    const double *guide_draws;   // point-cloud guidance: host-fed uniforms [S][5][N] (parity mode) or nullptr (device Philox)
     int step_base;           // index of the chain's first reverse step (0 unless a chain is resumed mid-way): noise and
                              // trajectory rows are indexed by step - step_base
 };
@@ -627,4 +628,102 @@ __global__ void clock_stamp_kernel(unsigned long long *out, const int *step_cur,
         out[2 * i] = __builtin_amdgcn_s_memtime();
         out[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Point-cloud shape guidance (models/molopt_score_model.py:699-740, applied to the predicted x0 of the steps with
+// t > grad_step, :583-586): an atom whose three nearest cloud points are on average farther than `radius` is pulled
+// towards their mean by a random fraction in [ratio, 0.8), re-checked, and pulled again up to five times.
+// The reference does this on the host (sklearn KD-tree, numpy float64, one D2H + H2D round trip per step); here it is a
+// kernel between the score evaluation and the posterior step: 16 lanes per atom scan the cloud (brute force, float64 as
+// the KD-tree), every atom runs its own five-iteration loop.  Uniform draws: the reference consumes np.random.random()
+// in the order of the currently-far atoms of each iteration; parity mode is fed the recorded draw of every
+// (step, iteration, atom), throughput mode uses Philox keyed by the same triple.
+// ---------------------------------------------------------------------------------------------
+struct PcGuideArgs {
+    float *pred_pos;          // [N][3] in/out
+    const double *cloud;      // [P][3]
+    const ChainParams *cp;
+    const int *step_cur;
+    int n_atoms, n_points, t_first, grad_step;
+    double radius;
+};
+
+struct Top3 { double d[3]; int i[3]; };
+SM_DEV void top3_insert(Top3 &t, double d, int i) {
+    if (d < t.d[2]) {
+        if (d < t.d[1]) {
+            t.d[2] = t.d[1]; t.i[2] = t.i[1];
+            if (d < t.d[0]) { t.d[1] = t.d[0]; t.i[1] = t.i[0]; t.d[0] = d; t.i[0] = i; }
+            else { t.d[1] = d; t.i[1] = i; }
+        } else { t.d[2] = d; t.i[2] = i; }
+    }
+}
+SM_DEV double shfl_xor_f64(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
+    return __hiloint2double(hi, lo);
+}
+// three nearest cloud points of p: squared distances ascending + indices, identical in all 16 lanes of the atom
+SM_DEV Top3 pc_query(const double *cloud, int n_points, const double (&p)[3], int l16) {
+    Top3 t{{1e300, 1e300, 1e300}, {-1, -1, -1}};
+    for (int c = l16; c < n_points; c += 16) {
+        const double dx = p[0] - cloud[c * 3], dy = p[1] - cloud[c * 3 + 1], dz = p[2] - cloud[c * 3 + 2];
+        top3_insert(t, (dx * dx + dy * dy) + dz * dz, c);
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        Top3 o;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o.d[k] = shfl_xor_f64(t.d[k], m); o.i[k] = __shfl_xor(t.i[k], m, 64); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (o.i[k] >= 0 && (o.d[k] < t.d[2] || (o.d[k] == t.d[2] && o.i[k] < t.i[2]))) {
+            // insert with an index tie-break so that both partners end with the same triple
+            Top3 u = t;
+            int pos = 2;
+            while (pos > 0 && (o.d[k] < u.d[pos - 1] || (o.d[k] == u.d[pos - 1] && o.i[k] < u.i[pos - 1]))) --pos;
+            for (int q = 2; q > pos; --q) { u.d[q] = u.d[q - 1]; u.i[q] = u.i[q - 1]; }
+            u.d[pos] = o.d[k]; u.i[pos] = o.i[k];
+            t = u;
+        }
+    }
+    return t;
+}
+
+__global__ void __launch_bounds__(256) pc_guidance_kernel(PcGuideArgs a) {
+    const int step = a.step_cur ? *a.step_cur : 0;
+    if (a.t_first - step <= a.grad_step) return;                   // `if i > grad_step` (molopt_score_model.py:585)
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int atom_raw = gid >> 4, l16 = gid & 15;
+    const int atom = atom_raw < a.n_atoms ? atom_raw : a.n_atoms - 1;
+    double p[3] = {(double)a.pred_pos[atom * 3], (double)a.pred_pos[atom * 3 + 1], (double)a.pred_pos[atom * 3 + 2]};
+    Top3 t = pc_query(a.cloud, a.n_points, p, l16);
+    bool far = (sqrt(t.d[0]) + sqrt(t.d[1]) + sqrt(t.d[2])) / 3.0 > a.radius;
+    bool changed = false;
+    const ChainParams cp = *a.cp;
+    for (int j = 0; j < 5; ++j) {
+        if (!__any(far)) break;
+        if (far) {
+            double u;
+            if (cp.guide_draws) {
+                u = cp.guide_draws[((size_t)(step - cp.step_base) * 5 + j) * a.n_atoms + atom];
+            } else {
+                Philox ph{(uint32_t)cp.seed, (uint32_t)(cp.seed >> 32)};
+                uint32_t r[4];
+                ph((uint32_t)atom, (uint32_t)step, (uint32_t)(100 + j), 0x9c1du, r);
+                u = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
+            }
+            const double scalar = u * (0.8 - 0.2) + 0.2;           // np.random.random() * (0.8 - ratio) + ratio, ratio = 0.2
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double nearest = (a.cloud[t.i[0] * 3 + k] + a.cloud[t.i[1] * 3 + k] + a.cloud[t.i[2] * 3 + k]) / 3.0;
+                p[k] = p[k] - scalar * (p[k] - nearest);
+            }
+            changed = true;
+        }
+        // the query is wave-uniform control flow (shuffles): lanes of atoms that are done run it on their final point
+        t = pc_query(a.cloud, a.n_points, p, l16);
+        if (far && (sqrt(t.d[0]) + sqrt(t.d[1]) + sqrt(t.d[2])) / 3.0 < a.radius) far = false;
+    }
+    if (changed && atom_raw < a.n_atoms && l16 < 3) a.pred_pos[atom * 3 + l16] = (float)(l16 == 0 ? p[0] : (l16 == 1 ? p[1] : p[2]));
 }

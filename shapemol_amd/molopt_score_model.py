@@ -28,7 +28,7 @@ from .diffusion import build_schedule_tables
 from .packing import pack_state_dict
 from .spec import ModelDims, state_dict_spec, RBF_CENTRES
 
-__all__ = ["ScorePosNet3D", "log_sample_categorical"]
+__all__ = ["ScorePosNet3D", "log_sample_categorical", "pointcloud_shape_guidance"]
 
 
 class _Params(nn.Module):
@@ -192,7 +192,7 @@ class ScorePosNet3D(nn.Module):
                          threshold_args=None, num_steps=None, center_pos_mode=None, use_grad=False, grad_lr=1,
                          shape_AE=None, use_mesh_data=None, use_pointcloud_data=None, grad_step=500,
                          guide_stren=0, bounds=None, *, noise=None, seed=None, return_traj=True, use_graph=True,
-                         first_step=0, _reuse_host_buffers=False):
+                         first_step=0, guide_draws=None, _reuse_host_buffers=False):
         """Reverse diffusion chain; same arguments and result dict as the reference.
 
         Extensions (keyword-only): ``noise=(eps, u)`` feeds host-chosen draws, eps (S,N,3) and u (S,N,C)
@@ -201,9 +201,12 @@ class ScorePosNet3D(nn.Module):
         ``return_traj=False`` skips the per-step trajectories (the lists come back empty).
         ``first_step=s`` resumes a chain at reverse step s (t = T-1-s) from the given state and runs ``num_steps``
         steps from there (the windowed full-length parity test; the reference always starts at T-1).
+        ``use_pointcloud_data=(point_clouds, kdtree, radius)`` with ``grad_step`` is the reference's point-cloud shape
+        guidance (``:583-586,699-740``) as a device kernel inside the step (the KD-tree is not used: brute-force float64
+        3-nearest search); ``guide_draws`` (S,5,N) float64 feeds the recorded ``np.random.random`` draws (parity mode).
         """
-        if use_mesh_data is not None or use_pointcloud_data is not None or use_grad:
-            raise NotImplementedError("mesh / point-cloud / gradient shape guidance is outside the accelerated path")
+        if use_mesh_data is not None or use_grad:
+            raise NotImplementedError("mesh / gradient shape guidance is outside the accelerated path")
         if self.cond_mask_prob == 0:
             assert guide_stren == 0
         if guide_stren:
@@ -229,6 +232,16 @@ class ScorePosNet3D(nn.Module):
                 raise ValueError("noise must be (eps (S,N,3), u (S,N,C))")
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
+        guided = use_pointcloud_data is not None
+        if guided:
+            cloud = np.ascontiguousarray(np.asarray(use_pointcloud_data[0], dtype=np.float64).reshape(-1, 3))
+            gd = None
+            if guide_draws is not None:
+                gd = _check_device_tensor("guide_draws", guide_draws, torch.float64)
+                if tuple(gd.shape) != (num_steps, 5, n):
+                    raise ValueError("guide_draws must be (S, 5, N) float64")
+            _lib.check(lib.shapemol_set_guidance(ctx, cloud.ctypes.data_as(C.c_void_p), cloud.shape[0], float(use_pointcloud_data[2]),
+                                                 int(grad_step), _ptr(gd)), "shapemol_set_guidance")
         tr = _lib.Traj()
         bufs = {}
         if return_traj:
@@ -254,6 +267,9 @@ class ScorePosNet3D(nn.Module):
                 lib.shapemol_set_option(ctx, b"first_step", 0)
             cur.wait_stream(side)
         _lib.check(rc, "shapemol_sample")
+        if guided:
+            torch.cuda.synchronize(dev)
+            _lib.check(lib.shapemol_set_guidance(ctx, None, 0, 0.0, 0, None), "shapemol_set_guidance")
         cur.synchronize()               # the reference returns finished results; also the point where input flags are read
         self.check_status()
         for t_ in (pos, v, batch, shape, eps, u, out_pos, out_v, *bufs.values()):
@@ -278,6 +294,33 @@ class ScorePosNet3D(nn.Module):
         else:
             res.update(pos_traj=[], v_traj=[], v0_traj=[], vt_traj=[], pos_cond_traj=[], v_cond_traj=[])
         return res
+
+    def pointcloud_shape_guidance(self, use_pointcloud_data, pred_ligand_pos, k=3, ratio=0.2, *, draws=None, seed=None):
+        """``pointcloud_shape_guidance`` of the reference (``models/molopt_score_model.py:699-740``) as one device kernel:
+        guides ``pred_ligand_pos`` (N,3) in place and returns it.  ``use_pointcloud_data = (point_clouds, kdtree, radius)``
+        as there (the KD-tree is not used).  ``draws`` (5,N) float64 device tensor: the uniform of every
+        (iteration, atom) (parity mode); otherwise device Philox keyed by ``seed``."""
+        if k != 3 or ratio != 0.2:
+            raise NotImplementedError("the device kernel implements the reference's defaults k=3, ratio=0.2")
+        pos = _check_device_tensor("pred_ligand_pos", pred_ligand_pos, torch.float32)
+        if pos.data_ptr() != pred_ligand_pos.data_ptr():
+            raise ValueError("pred_ligand_pos must be contiguous (it is updated in place)")
+        dev = pos.device
+        ctx, lib = self._context(dev), _lib.load()
+        cloud = np.ascontiguousarray(np.asarray(use_pointcloud_data[0], dtype=np.float64).reshape(-1, 3))
+        gd = None if draws is None else _check_device_tensor("draws", draws, torch.float64)
+        if gd is not None and tuple(gd.shape) != (5, pos.shape[0]):
+            raise ValueError("draws must be (5, N) float64")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if gd is None else 0
+        _lib.check(lib.shapemol_set_guidance(ctx, cloud.ctypes.data_as(C.c_void_p), cloud.shape[0], float(use_pointcloud_data[2]), 0, None),
+                   "shapemol_set_guidance")
+        with torch.cuda.device(dev):
+            rc = lib.shapemol_guide_points(ctx, _ptr(pos), pos.shape[0], _ptr(gd), C.c_uint64(seed), _stream_ptr(torch.cuda.current_stream(dev)))
+        _lib.check(rc, "shapemol_guide_points")
+        torch.cuda.synchronize(dev)
+        _lib.check(lib.shapemol_set_guidance(ctx, None, 0, 0.0, 0, None), "shapemol_set_guidance")
+        return pred_ligand_pos
 
     def check_status(self):
         """Synchronise and raise if the last forward / sample_diffusion saw an invalid input (batch vector not sorted

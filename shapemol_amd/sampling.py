@@ -93,7 +93,8 @@ def _traj_to_host(r, name):
 def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device="cuda:0", num_steps=None,
                             pos_only=False, center_pos_mode="none", sample_func=None, threshold_type=None,
                             threshold_args=None, sample_num_atoms="prior", bounds=None, ref_num_atoms=None,
-                            ref_atom_feature=None, guide_stren=0, seed=None, use_graph=True, host_rng=False):
+                            ref_atom_feature=None, guide_stren=0, seed=None, use_graph=True, host_rng=False,
+                            use_pointcloud_data=None, grad_step=1000):
     """``sample_diffusion_ligand`` of the reference for one shape condition.
 
     shape_emb        (32, 3) latent of the condition (``data.shape_emb``); repeated per molecule of a batch.
@@ -108,6 +109,9 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
                      and ``rand_like(N, C)`` (``:99``) -- and is fed to the device chain: ``np.random.seed(s);
                      torch.manual_seed(s)`` then reproduces the reference's CPU run from the seeds alone.  Default False:
                      the chain's noise is generated on the device (Philox), as the reference's own CUDA run draws on the GPU.
+    use_pointcloud_data, grad_step   ``(point_clouds, kdtree, radius)`` and the time step below which guidance stops
+                     (``config.sample.use_pointcloud*`` / ``grad_step``, ``scripts/sample_diffusion.py:237-243``): the point-cloud
+                     shape guidance runs as a device kernel inside every step with t > grad_step.
     shape_emb        may also be (n_data, 32, 3), one condition per molecule of a single batch (fixtures).
 
     Returns the reference's 9-tuple: ``(pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj,
@@ -168,6 +172,7 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
             ligand_shape=(shape_emb if per_mol_shapes else shape_emb.repeat(n_data, 1, 1)).to(dev).reshape(n_data, -1),
             threshold_type=threshold_type, threshold_args=threshold_args, num_steps=num_steps,
             center_pos_mode=center_pos_mode, guide_stren=guide_stren, bounds=bounds,
+            use_pointcloud_data=use_pointcloud_data, grad_step=grad_step,
             seed=None if seed is None else int(seed) + i, use_graph=use_graph, **noise_kw,
             **({"_reuse_host_buffers": "device"} if getattr(model, "_accelerated", False) else {}))
         cum = np.cumsum([0] + ligand_num_atoms)

@@ -8,6 +8,7 @@ because these take tens of CPU-minutes while make_golden.py's set regenerates in
     python tests/golden/make_golden_r2.py b256      # configs[1]: B=256 x 1000 steps   (~30 min)
     python tests/golden/make_golden_r2.py b1024     # configs[2]: B=1024 x 50 steps    (~6 min)
     python tests/golden/make_golden_r2.py k32       # configs[4]: <=80 atoms, k=32, L=8, B=64
+    python tests/golden/make_golden_r2.py guide     # point-cloud shape guidance: the function alone and inside a chain
     python tests/golden/make_golden_r2.py all
 
 Noise is the hash noise of synth.step_noise (a pure function of (seed, step)), so the fixtures
@@ -54,6 +55,82 @@ def chain(model, tag, B, S, seed, every, head, atoms_range=None, max_atoms=None)
     print(f"chain {tag}: N = {n}, {S} steps in {time.time() - t0:.0f} s", flush=True)
 
 
+class GuideRecorder:
+    """Stands in for the sklearn KD-tree handed to the reference's pointcloud_shape_guidance
+    (models/molopt_score_model.py:699-740) and for np.random.random during the call: answers every query with a real
+    KDTree and mirrors the function's control flow to learn WHICH atoms receive each uniform draw (the function draws
+    one value per currently-far atom, in index order).  Yields the dense table draws[step][iteration][atom]."""
+
+    def __init__(self, cloud, radius, n_atoms):
+        from sklearn.neighbors import KDTree
+        self.tree, self.radius, self.n = KDTree(cloud), radius, n_atoms
+        self.steps, self.far, self.it, self.fresh = [], None, 0, True
+
+    def query(self, x, k=3):
+        d, i = self.tree.query(x, k=k)
+        m = d.mean(1)
+        if self.fresh:                       # first query of a call: all atoms
+            assert len(x) == self.n
+            self.steps.append(np.full((5, self.n), 0.5))
+            self.far, self.it = np.where(m > self.radius)[0], 0
+            self.fresh = len(self.far) == 0
+        else:                                # re-check of the pulled atoms
+            self.far = self.far[~(m < self.radius)]
+            self.it += 1
+            self.fresh = len(self.far) == 0 or self.it == 5
+        return d, i
+
+    def random(self, n):
+        assert not self.fresh and n == len(self.far)
+        u = self._rs.random_sample(n)
+        self.steps[-1][self.it, self.far] = u
+        return u
+
+    @contextlib.contextmanager
+    def active(self, seed):
+        self._rs = np.random.RandomState(seed)
+        real_random, real_cuda = np.random.random, torch.Tensor.cuda
+        np.random.random = self.random
+        torch.Tensor.cuda = lambda t, *a, **k: t          # the reference hard-codes .cuda() (:738); this harness runs on the CPU
+        try:
+            yield self
+        finally:
+            np.random.random, torch.Tensor.cuda = real_random, real_cuda
+
+
+def guidance_fixtures():
+    from models.molopt_score_model import pointcloud_shape_guidance
+    cloud = (synth.hash_normal((512, 3), 301, 5) * 1.2).astype(np.float64)
+    radius = 0.2
+    # (A) the function alone: atoms scattered around and beyond the cloud
+    n = 300
+    pred = (synth.hash_normal((n, 3), 302, 5) * 1.6).astype(np.float32)
+    rec = GuideRecorder(cloud, radius, n)
+    with rec.active(77):
+        out = pointcloud_shape_guidance((cloud, rec, radius), torch.from_numpy(pred.copy()))
+    np.savez_compressed(os.path.join(HERE, "guidance_fn.npz"), cloud=cloud, radius=radius, pred=pred, out=out.numpy(),
+                        draws=rec.steps[0])
+    print("guidance_fn: moved atoms", int((out.numpy() != pred).any(1).sum()), "of", n, flush=True)
+    # (B) inside a chain: B = 4, 20 reverse steps, guided while t > 990
+    model, _ = G.load_reference_model()
+    G.synthetic_load(model, seed=7)
+    B, S, seed, grad_step = 4, 20, 21, 990
+    bb = synth.synthetic_batch(B, seed=seed)
+    na = len(bb["batch"])
+    eps, u = zip(*[synth.step_noise(na, 15, s, seed=seed) for s in range(S)])
+    rec = GuideRecorder(cloud, radius, na)
+    with G.fed_noise(list(eps), list(u)), rec.active(78), contextlib.redirect_stdout(open(os.devnull, "w")):
+        r = model.sample_diffusion(t_(bb["init_pos"]), t_(bb["init_v"]), t_(bb["batch"]), t_(bb["shape"]).view(B, -1), num_steps=S,
+                                   center_pos_mode="none", use_pointcloud_data=(cloud, rec, radius), grad_step=grad_step)
+    draws = np.full((S, 5, na), 0.5)
+    draws[:len(rec.steps)] = np.stack(rec.steps)          # guided steps come first (t = 999 ... grad_step + 1)
+    np.savez_compressed(os.path.join(HERE, "chain_guided_b4_s20.npz"), B=B, S=S, seed=seed, grad_step=grad_step, cloud=cloud,
+                        radius=radius, draws=draws, guided_steps=len(rec.steps), pos=r["pos"].numpy(), v=r["v"].numpy(),
+                        pos_traj=torch.stack(r["pos_traj"]).numpy(), v_traj=torch.stack(r["v_traj"]).numpy(),
+                        pos_cond_traj=torch.stack(r["pos_cond_traj"]).numpy())
+    print("chain_guided: guided steps", len(rec.steps), "of", S, flush=True)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -64,6 +141,9 @@ def main():
             chain(model, "b1024_s50", 1024, 50, 14, every=10, head=2, max_atoms=38)
         if what in ("b256", "all"):
             chain(model, "b256_s1000", 256, 1000, 13, every=50, head=4, max_atoms=38)
+    if what in ("guide", "all"):
+        G.install_stand_ins()
+        guidance_fixtures()
     if what in ("k32", "all"):
         # configs[4] analogue: 40-80 atom molecules, knn = 32, full depth
         m2, _ = G.load_reference_model(dict(knn=32))

@@ -596,3 +596,53 @@ def test_forward_b1024_edge_tile_variants(tiles):
         m.set_option("edge_tiles", 2)
     for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
         assert maxabs(out[k], ref[k]) < FWD_TOL, k
+
+
+# ---- point-cloud shape guidance ------------------------------------------------------
+def test_pointcloud_guidance_function_golden():
+    """The guidance kernel on its own against the reference function (sklearn KD-tree + numpy) on the recorded draws:
+    the same atoms are pulled, to the same positions (float64 arithmetic, float32 result)."""
+    from util import record
+    m = hip_model()
+    f = golden("guidance_fn.npz")
+    pos = T(f["pred"].copy(), DEV)
+    out = m.pointcloud_shape_guidance((f["cloud"], None, float(f["radius"])), pos, draws=T(f["draws"], DEV))
+    got = out.cpu().numpy()
+    moved_ref = (f["out"] != f["pred"]).any(1)
+    assert np.array_equal((got != f["pred"]).any(1), moved_ref) and moved_ref.sum() > 100
+    err = np.abs(got.astype(np.float64) - f["out"]).max()
+    record("pointcloud_guidance_function_golden", moved=int(moved_ref.sum()), max_err=float(err))
+    assert err < 1e-6
+    # throughput mode (device Philox): deterministic per seed, and (nearly) every pulled atom ends closer to the cloud
+    a = m.pointcloud_shape_guidance((f["cloud"], None, float(f["radius"])), T(f["pred"].copy(), DEV), seed=5).cpu().numpy()
+    b = m.pointcloud_shape_guidance((f["cloud"], None, float(f["radius"])), T(f["pred"].copy(), DEV), seed=5).cpu().numpy()
+    assert np.array_equal(a, b) and np.array_equal((a != f["pred"]).any(1), moved_ref)
+
+    def mean3(x):
+        d = np.sqrt(((x[:, None, :].astype(np.float64) - f["cloud"][None]) ** 2).sum(-1))
+        return np.sort(d, 1)[:, :3].mean(1)
+    assert (mean3(a)[moved_ref] < mean3(f["pred"])[moved_ref]).mean() > 0.9
+
+
+def test_guided_chain_golden():
+    """sample_diffusion(use_pointcloud_data=..., grad_step=990): 20 reverse steps, the first 9 guided, against the
+    reference's chain (recorded np.random.random draws per step / iteration / atom)."""
+    from util import record
+    m = hip_model()
+    c = golden("chain_guided_b4_s20.npz")
+    B, S, seed = int(c["B"]), int(c["S"]), int(c["seed"])
+    bb = synth.synthetic_batch(B, seed=seed)
+    eps, u = hash_noise(len(bb["batch"]), S, seed)
+    for use_graph in (True, False):
+        r = m.sample_diffusion(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV).view(B, -1),
+                               num_steps=S, center_pos_mode="none", noise=(T(eps, DEV), T(u, DEV)), use_graph=use_graph,
+                               use_pointcloud_data=(c["cloud"], None, float(c["radius"])), grad_step=int(c["grad_step"]),
+                               guide_draws=T(c["draws"], DEV))
+        e_pos, e_cond = maxabs(r["pos"], c["pos"]), maxabs(torch.stack(r["pos_cond_traj"]), c["pos_cond_traj"])
+        record("guided_chain_golden", use_graph=use_graph, pos_end=e_pos, pos_cond_traj=e_cond)
+        assert np.array_equal(r["v"].cpu().numpy(), c["v"])
+        assert np.array_equal(torch.stack(r["v_traj"]).numpy(), c["v_traj"])
+        assert e_pos < POS_TOL and e_cond < POS_TOL
+    # and an unguided chain afterwards is unaffected (guidance is per call)
+    r0 = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
+    assert maxabs(r0["pos"], c["pos"]) > 1e-3

@@ -78,3 +78,26 @@ def test_chain_hash_noise(tag):
     assert np.array_equal(torch.stack(r["v_traj"][::every]).numpy(), c["v_traj_sub"])
     assert maxabs(r["pos"], c["pos"]) < 1e-4
     assert maxabs(torch.stack(r["pos_traj"][::every]), c["pos_traj_sub"]) < 1e-4
+
+
+def test_guidance_function_golden():
+    """The oracle's point-cloud guidance against the reference function's output (sklearn KD-tree, numpy) on the
+    recorded draws: the same atoms move, to the same float32 positions."""
+    f = golden("guidance_fn.npz")
+    out = O.pointcloud_shape_guidance(f["cloud"], float(f["radius"]), f["pred"], f["draws"])
+    assert np.array_equal((out != f["pred"]).any(1), (f["out"] != f["pred"]).any(1))
+    assert np.abs(out.astype(np.float64) - f["out"]).max() < 1e-6
+
+
+def test_guided_chain_golden():
+    """20 reverse steps with guidance on the first 9 (t > 990) against the reference's chain."""
+    sd, dm, _, _ = oracle_model()
+    c = golden("chain_guided_b4_s20.npz")
+    B, S, seed = int(c["B"]), int(c["S"]), int(c["seed"])
+    bb = synth.synthetic_batch(B, seed=seed)
+    eps, u = hash_noise(len(bb["batch"]), S, seed)
+    r = O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S, lambda s: (eps[s], u[s]),
+                       guidance=(c["cloud"], float(c["radius"]), int(c["grad_step"]), c["draws"]))
+    assert np.array_equal(r["v"].numpy(), c["v"])
+    assert maxabs(r["pos"], c["pos"]) < 1e-4
+    assert maxabs(torch.stack(r["pos_cond_traj"]), c["pos_cond_traj"]) < 1e-4
