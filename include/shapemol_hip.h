@@ -131,6 +131,22 @@ int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, co
                                     int64_t n_rows, int32_t n_classes, uint64_t seed,
                                     int64_t *out_index, void *stream);
 
+/* ---- frozen shape encoder ------------------------------------------------------------
+ * VN_DGCNN_Encoder.forward (models/shape_pointcloud_modelAE.py:207-255) with get_graph_feature_cross / dense knn
+ * (models/shape_vn_layers.py:257-292): point clouds (B,N,3) -> shape latents (B,latent_dim,3), the `shape_emb` the
+ * diffusion model is conditioned on (utils/shape.py:240-283).  Batch-norm runs on batch statistics, as the reference's
+ * auto-encoder does (it is never put in eval mode).  hidden_dim 128, num_k 20 (the shipped checkpoint's config).
+ * weights (HOST, float32, shapemol_se_weight_count of them): conv_pos {map_to_feat (C,2), bn weight (C), bn bias (C),
+ * map_to_dir (C,2)}; per block {map_to_feat (C,2C), bn weight, bn bias, map_to_dir (C,2C)}; conv_c {map_to_feat
+ * (latent,L*C), bn weight (latent), bn bias (latent), map_to_dir (L*C)}. */
+typedef struct shapemol_se_ctx shapemol_se_ctx;
+size_t shapemol_se_weight_count(int32_t hidden_dim, int32_t latent_dim, int32_t layer_num);
+int shapemol_se_create(int32_t hidden_dim, int32_t latent_dim, int32_t layer_num, int32_t num_k, const float *weights,
+                       size_t n_weights, int device, shapemol_se_ctx **out);
+void shapemol_se_destroy(shapemol_se_ctx *ctx);
+/* d_points (B,N,3) f32 DEVICE, N a multiple of 16; d_out (B,latent_dim,3) f32 DEVICE. */
+int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_shapes, int64_t n_points, float *d_out, void *stream);
+
 /* ---- diagnostics (used by the parity tests and the bench; not needed by a caller) ---- */
 /* options: "first_step" (the following _sample calls resume a chain at reverse step v, i.e. at t = T-1-v, from the
  *                        state given as d_init_pos / d_init_v; noise and trajectory rows stay indexed from 0; default 0.

@@ -18,6 +18,7 @@ EXPORTS = (
     "shapemol_destroy", "shapemol_reserve", "shapemol_score", "shapemol_sample",
     "shapemol_log_sample_categorical", "shapemol_set_option", "shapemol_debug_read",
     "shapemol_profile_begin", "shapemol_profile_end", "shapemol_status", "shapemol_set_guidance", "shapemol_guide_points",
+    "shapemol_se_weight_count", "shapemol_se_create", "shapemol_se_destroy", "shapemol_se_encode",
 )
 
 
@@ -81,6 +82,12 @@ def load():
     lib.shapemol_status.argtypes = [vp, vp]
     lib.shapemol_set_guidance.argtypes = [vp, vp, i64, C.c_double, i32, vp]
     lib.shapemol_guide_points.argtypes = [vp, vp, i64, vp, u64, vp]
+    lib.shapemol_se_weight_count.restype = C.c_size_t
+    lib.shapemol_se_weight_count.argtypes = [i32, i32, i32]
+    lib.shapemol_se_create.argtypes = [i32, i32, i32, i32, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.shapemol_se_destroy.argtypes = [vp]
+    lib.shapemol_se_destroy.restype = None
+    lib.shapemol_se_encode.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.shapemol_profile_begin.argtypes = [vp]
     lib.shapemol_profile_end.argtypes = [vp, vp, vp, vp, C.c_int]
     if lib.shapemol_abi_version() != ABI_VERSION:

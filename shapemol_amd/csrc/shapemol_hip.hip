@@ -892,6 +892,7 @@ int check_cfg(const shapemol_config &g) {
 extern "C" {
 
 int shapemol_abi_version(void) { return SHAPEMOL_ABI_VERSION; }
+void shapemol_set_error_(const char *msg) { g_err = msg ? msg : ""; }      // other translation units of the library
 const char *shapemol_last_error(void) { return g_err.c_str(); }
 
 size_t shapemol_weight_count(const shapemol_config *cfg) { return cfg ? weight_count(*cfg) : 0; }

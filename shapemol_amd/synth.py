@@ -140,3 +140,20 @@ def synthetic_state_dict(model_cfg, seed=7, num_classes=15):
         if k.endswith("distance_expansion.offset"):
             out[k] = np.asarray(RBF_CENTRES, np.float32)
     return {k: out[k] for k in spec}
+
+
+def shape_encoder_state_dict(hidden=128, latent=32, layers=4, seed=17):
+    """Hash-filled weights of the shape encoder under the keys of shapemol_amd.shape_encoder.VN_DGCNN_Encoder
+    (conv_pos.*, blocks.{i}.*, conv_c.*; batch-norm running statistics are not part of the forward)."""
+    spec = {}
+
+    def vn(prefix, cin, cout, shared=False):
+        spec[prefix + ".map_to_feat.weight"] = ((cout, cin), "weight", cin)
+        spec[prefix + ".batchnorm.bn.weight"] = ((cout,), "norm_weight", 0)
+        spec[prefix + ".batchnorm.bn.bias"] = ((cout,), "norm_bias", 0)
+        spec[prefix + ".map_to_dir.weight"] = ((1 if shared else cout, cin), "weight", cin)
+    vn("conv_pos", 2, hidden)
+    for i in range(layers):
+        vn(f"blocks.{i}", 2 * hidden, hidden)
+    vn("conv_c", layers * hidden, latent, shared=True)
+    return fill_state_dict(spec, seed=seed)

@@ -9,6 +9,7 @@ because these take tens of CPU-minutes while make_golden.py's set regenerates in
     python tests/golden/make_golden_r2.py b1024     # configs[2]: B=1024 x 50 steps    (~6 min)
     python tests/golden/make_golden_r2.py k32       # configs[4]: <=80 atoms, k=32, L=8, B=64
     python tests/golden/make_golden_r2.py guide     # point-cloud shape guidance: the function alone and inside a chain
+    python tests/golden/make_golden_r2.py se        # frozen shape encoder (VN_DGCNN_Encoder), 3 clouds of 512 points
     python tests/golden/make_golden_r2.py all
 
 Noise is the hash noise of synth.step_noise (a pure function of (seed, step)), so the fixtures
@@ -131,6 +132,29 @@ def guidance_fixtures():
     print("chain_guided: guided steps", len(rec.steps), "of", S, flush=True)
 
 
+def shape_encoder_fixture():
+    from models.shape_pointcloud_modelAE import VN_DGCNN_Encoder
+    hidden, latent, layers, k = 128, 32, 4, 20                     # config.model of trained_models/se_model.pt
+    enc = VN_DGCNN_Encoder(hidden, latent, layers, k)              # stays in train mode, as utils/shape.py:226-238 leaves it
+    sd = synth.shape_encoder_state_dict(hidden, latent, layers, seed=17)
+    def load(mod, prefix):
+        mod.map_to_feat.weight.data = t_(sd[prefix + ".map_to_feat.weight"])
+        mod.batchnorm.bn.weight.data = t_(sd[prefix + ".batchnorm.bn.weight"])
+        mod.batchnorm.bn.bias.data = t_(sd[prefix + ".batchnorm.bn.bias"])
+        mod.map_to_dir.weight.data = t_(sd[prefix + ".map_to_dir.weight"])
+    load(enc.conv_pos, "conv_pos")
+    for i, blk in enumerate(enc.blocks):
+        load(blk, f"blocks.{i}")
+    load(enc.conv_c, "conv_c")
+    B, N = 3, 512
+    pts = (synth.hash_normal((B, N, 3), 401, 9) * np.array([1.5, 1.0, 0.6], np.float32)).astype(np.float32)   # anisotropic blobs
+    with torch.no_grad():
+        z = enc(t_(pts).unsqueeze(1))
+    np.savez_compressed(os.path.join(HERE, "shape_encoder.npz"), points=pts, latent=z.numpy(), hidden=hidden, latent_dim=latent,
+                        layers=layers, k=k, seed=17)
+    print("shape_encoder:", tuple(z.shape), "max |z|", float(z.abs().max()), flush=True)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -141,6 +165,9 @@ def main():
             chain(model, "b1024_s50", 1024, 50, 14, every=10, head=2, max_atoms=38)
         if what in ("b256", "all"):
             chain(model, "b256_s1000", 256, 1000, 13, every=50, head=4, max_atoms=38)
+    if what in ("se", "all"):
+        G.install_stand_ins()
+        shape_encoder_fixture()
     if what in ("guide", "all"):
         G.install_stand_ins()
         guidance_fixtures()

@@ -646,3 +646,40 @@ def test_guided_chain_golden():
     # and an unguided chain afterwards is unaffected (guidance is per call)
     r0 = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
     assert maxabs(r0["pos"], c["pos"]) > 1e-3
+
+
+# ---- frozen shape encoder --------------------------------------------------------------
+def _hip_shape_encoder(f):
+    import shapemol_amd
+    enc = shapemol_amd.VN_DGCNN_Encoder(int(f["hidden"]), int(f["latent_dim"]), int(f["layers"]), int(f["k"]))
+    sd = synth.shape_encoder_state_dict(int(f["hidden"]), int(f["latent_dim"]), int(f["layers"]), int(f["seed"]))
+    missing, unexpected = enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith(("running_mean", "running_var", "num_batches_tracked")) for k in missing)
+    return enc.to(DEV)
+
+
+def test_shape_encoder_golden():
+    """VN_DGCNN_Encoder on the device against the reference class's own output (3 clouds of 512 points, batch-norm on
+    batch statistics, kNN in feature space): the (B, 32, 3) shape latents within 2e-5."""
+    from util import record
+    f = golden("shape_encoder.npz")
+    enc = _hip_shape_encoder(f)
+    z = enc(T(f["points"], DEV).unsqueeze(1))
+    err = maxabs(z, f["latent"])
+    record("shape_encoder_golden", max_err=err, max_abs=float(np.abs(f["latent"]).max()))
+    assert tuple(z.shape) == (3, 32, 3) and err < 2e-5
+
+
+def test_shape_encoder_equivariance_and_oracle():
+    """Rotating the clouds rotates the latents (vector-neuron network), and another batch size agrees with the CPU oracle."""
+    from oracle import shape_encoder_oracle as SE
+    f = golden("shape_encoder.npz")
+    enc = _hip_shape_encoder(f)
+    Q = _rotation(3)
+    pts = f["points"][:2]
+    z = enc(T(pts, DEV)).cpu().numpy()
+    zr = enc(T(pts @ Q.T, DEV)).cpu().numpy()
+    assert np.abs(z @ Q.T - zr).max() < 2e-5
+    sd = {k: torch.from_numpy(v) for k, v in synth.shape_encoder_state_dict(128, 32, 4, int(f["seed"])).items()}
+    ref = SE.encode(sd, torch.from_numpy(pts), 4, 20).numpy()
+    assert np.abs(z - ref).max() < 2e-5

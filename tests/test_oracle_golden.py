@@ -101,3 +101,13 @@ def test_guided_chain_golden():
     assert np.array_equal(r["v"].numpy(), c["v"])
     assert maxabs(r["pos"], c["pos"]) < 1e-4
     assert maxabs(torch.stack(r["pos_cond_traj"]), c["pos_cond_traj"]) < 1e-4
+
+
+def test_shape_encoder_oracle_golden():
+    """oracle/shape_encoder_oracle.py against the reference's own VN_DGCNN_Encoder (hash-filled weights, 3 clouds)."""
+    from oracle import shape_encoder_oracle as SE
+    f = golden("shape_encoder.npz")
+    sd = {k: torch.from_numpy(v) for k, v in synth.shape_encoder_state_dict(int(f["hidden"]), int(f["latent_dim"]), int(f["layers"]), int(f["seed"])).items()}
+    z = SE.encode(sd, torch.from_numpy(f["points"]), int(f["layers"]), int(f["k"]))
+    assert maxabs(z, f["latent"]) < 2e-5
+
