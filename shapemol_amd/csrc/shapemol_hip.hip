@@ -440,7 +440,8 @@ struct shapemol_ctx {
     const float *last_h = nullptr, *last_x = nullptr;
     // options
     int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 3, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
-    int edge_tiles = 2;         // multi-job launches of the f16 edge kernels: 2 = two tiles per wave-job (8 waves), 1 = one tile (<= 12 waves)
+    int edge_tiles = 0;         // f16 edge kernels when the waves have several jobs: 0 = sliced launches of the one-job kernel [default],
+                                // 1 = one looping launch (one tile per wave-job), 2 = one looping launch, two tiles per wave-job (8 waves)
     float hid_max = 0.f;        // bound of the edge MLPs' hidden activations (LayerNorm outputs): must fit fp16 for edge_bf16 = 3
     int num_cu = 256;
     // point-cloud shape guidance (shapemol_set_guidance)
@@ -619,16 +620,24 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
         const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
         const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
         const bool one = njobs <= grid * waves;      // every wave has at most one job: straight-line instantiation
-        if (one || c->edge_tiles != 2) {
-            const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
-                               + (H2X ? (size_t)vn_red_doubles(waves, H / 8) * 8 + (size_t)waves * apj * 48 * 4 : 0);
-            if (KP == 8) {
-                if (one) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
-                else LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
-            } else {
-                if (one) LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(grid), dim3(waves * 64), shm, s, a));
-                else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+        const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
+                           + (H2X ? (size_t)vn_red_doubles(waves, H / 8) * 8 + (size_t)waves * apj * 48 * 4 : 0);
+        if (one || c->edge_tiles == 0) {
+            // larger batches (edge_tiles = 0): several launches of the straight-line instantiation, each over a slice of
+            // grid x waves jobs (no spills, full overlap inside a launch; the image fill is paid per slice)
+            const int per = grid * waves;
+            for (int base = 0; base < njobs; base += per) {
+                Edge16Args b = a;
+                b.job_base = base; b.job_end = std::min(njobs, base + per);
+                const int g2 = std::max(1, std::min(grid, (b.job_end - base + waves - 1) / waves));
+                if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(g2), dim3(waves * 64), shm, s, b));
+                else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(g2), dim3(waves * 64), shm, s, b));
             }
+            return 0;
+        }
+        if (c->edge_tiles == 1) {
+            if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+            else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
             return 0;
         }
     }
@@ -1097,7 +1106,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
         if (value == 3 && c->hid_max > 6.0e4f) return fail("edge_bf16 = 3: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights");
         c->edge_bf16 = (int)value;
     }
-    else if (k == "edge_tiles") { if (value != 1 && value != 2) return fail("edge_tiles must be 1 or 2"); c->edge_tiles = (int)value; }
+    else if (k == "edge_tiles") { if (value < 0 || value > 2) return fail("edge_tiles must be 0, 1 or 2"); c->edge_tiles = (int)value; }
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "chain_bf16") c->chain_bf16 = (int)value;
     else if (k == "vn_fuse") c->vn_fuse = (int)value;

@@ -111,6 +111,7 @@ struct Edge16Args {
     const float *ew;        // [N][KP]
     float *out;             // x2h: [N][H]; h2x: [N][16][3]
     int n_atoms, ld_pre;
+    int job_base, job_end;            // edge16_kernel: this launch covers jobs [job_base, job_end) (job_end = 0: all of them)
     unsigned long long *stamps;       // diagnostic build only
     EdgeFusedArgs::VnFuse vn;         // h2x: VN-linear + batch statistics behind the attention (enable = 0 or 2)
 };
@@ -133,9 +134,10 @@ edge16_kernel(Edge16Args a) {
     const int n = lane & 15, g = lane >> 4;
     float cen[5];
     rbf_centres(g, cen);
-    const int njobs = (a.n_atoms + APJ - 1) / APJ;
+    const int njobs_all = (a.n_atoms + APJ - 1) / APJ;
+    const int njobs = a.job_end > 0 ? min(a.job_end, njobs_all) : njobs_all;       // a launch may cover a slice of the jobs
     const int jstride = gridDim.x * nwave;
-    const int job0 = blockIdx.x * nwave + wave;
+    const int job0 = a.job_base + blockIdx.x * nwave + wave;
 
     int atom = 0, jn = 0, edge = 0;
     bool atom_ok = false, ok = false;
@@ -146,20 +148,22 @@ edge16_kernel(Edge16Args a) {
 
     // the key MLP's rows are requested up front: the centre atom's first (they do not wait for the neighbour index),
     // then the neighbour's
-    auto request = [&](int jb) {
+    auto locate = [&](int jb) {      // -> the job's neighbour index (a load: issue it before anything else of the job)
         const int atom_raw = jb * APJ + n / SEGW;
         atom_ok = atom_raw < a.n_atoms;
         atom = atom_ok ? atom_raw : a.n_atoms - 1;
         edge = atom * KP + n % SEGW;
-        const int jraw = a.nbr[edge];
-        const float *pi = a.pre + (size_t)atom * a.ld_pre;
+        return a.nbr[edge];
+    };
+    auto request = [&](int jraw) {
+        const float *pi = a.pre + (size_t)(SM_ABL(17) ? 0 : atom) * a.ld_pre;
 #pragma unroll
         for (int t = 0; t < NT; ++t) ga[t] = ldg4(pi + 16 * t + 4 * g);
 #pragma unroll
         for (int k = 0; k < 3; ++k) xi[k] = a.x[atom * 3 + k];
         ok = atom_ok && jraw >= 0;
         jn = ok ? jraw : atom;
-        const float *pj = a.pre + (size_t)jn * a.ld_pre + H;
+        const float *pj = a.pre + (size_t)(SM_ABL(17) ? 0 : jn) * a.ld_pre + H;
 #pragma unroll
         for (int t = 0; t < NT; ++t) gb[t] = ldg4(pj + 16 * t + 4 * g);
 #pragma unroll
@@ -169,7 +173,7 @@ edge16_kernel(Edge16Args a) {
     // the value MLP's rows and the query row are requested once the key rows have been consumed (register budget): they
     // fly under the key MLP's hidden layer (all of whose other operands come from LDS)
     auto request_2 = [&]() {
-        const float *pi = a.pre + (size_t)atom * a.ld_pre + 2 * H, *pj = a.pre + (size_t)jn * a.ld_pre + 3 * H;
+        const float *pi = a.pre + (size_t)(SM_ABL(17) ? 0 : atom) * a.ld_pre + 2 * H, *pj = a.pre + (size_t)(SM_ABL(17) ? 0 : jn) * a.ld_pre + 3 * H;
 #pragma unroll
         for (int t = 0; t < NT; ++t) { gav[t] = ldg4(pi + 16 * t + 4 * g); gbv[t] = ldg4(pj + 16 * t + 4 * g); }
         const float *qrow = a.q + (size_t)atom * H + 4 * g;
@@ -201,9 +205,16 @@ edge16_kernel(Edge16Args a) {
     const bool have0 = job0 < njobs;
     SM_TICK(a.stamps, 0);
     // both weight images by LDS-DMA (asynchronous, no register staging); the job's row gathers fly beside them
-    dma_to_lds(lds, a.image_k, IMK::TOTAL / 4, wave, nwave, lane);
-    dma_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, wave, nwave, lane);
-    if (have0) request(job0);
+    // Order of the wave's memory operations (they complete in order, and the compiler cannot count the DMA pieces of a
+    // loop: it waits for ALL outstanding operations before the first dependent address): neighbour index -> the job's
+    // row gathers (the long pole, ~3 us from the Infinity Cache) -> image DMA (1.7 us, lands meanwhile).
+    // (SM_ABL(bit): timing-attribution builds only, build.sh --ablate MASK: 16 image DMA, 17 row gathers, 18 hidden layers,
+    //  19 key second Linear + softmax, 20 value second Linear)
+    if (have0) request(locate(job0));
+    if (!SM_ABL(16)) {
+        dma_to_lds(lds, a.image_k, IMK::TOTAL / 4, wave, nwave, lane);
+        dma_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, wave, nwave, lane);
+    }
     __syncthreads();
     SM_TICK(a.stamps, 1);
 
@@ -213,12 +224,12 @@ edge16_kernel(Edge16Args a) {
     // fused coordinate update (h2x): scratch behind the images
     double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);
     float *vn_o = reinterpret_cast<float *>(vn_red + vn_red_doubles(nwave, HD)) + wave * (APJ * 48);   // this wave's attention rows [APJ][16][3]
-    const bool one_job = njobs <= jstride;
+    const bool one_job = njobs - a.job_base <= jstride;
 
     bool first = true;
     for (int job = job0; job < njobs; job += jstride) {
         if constexpr (!ONE) asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
-        if (!first) request(job);
+        if (!first) request(locate(job));
         first = false;
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         u32x4 rh = {0u, 0u, 0u, 0u}, rl = {0u, 0u, 0u, 0u};
@@ -232,14 +243,26 @@ edge16_kernel(Edge16Args a) {
         }
         // ---- hidden activations of both MLPs, then the two second Linears back to back from registers ----------------
         u32x4 kh[NT / 2], kl[NT / 2], vh[NT / 2], vl[NT / 2];
-        hidden(imk, IMK{}, ga, gb, rh, rl, kh, kl, request_2);
-        SM_TICK(a.stamps, 2);
-        hidden(imv, IMV{}, gav, gbv, rh, rl, vh, vl, []() {});
+        if (!SM_ABL(18)) {
+            hidden(imk, IMK{}, ga, gb, rh, rl, kh, kl, request_2);
+            SM_TICK(a.stamps, 2);
+            hidden(imv, IMV{}, gav, gbv, rh, rl, vh, vl, []() {});
+        } else {
+            request_2();
+#pragma unroll
+            for (int b = 0; b < NT / 2; ++b) {
+                kh[b] = u32x4{__builtin_bit_cast(unsigned, ga[b].x + gb[b].x), rh[1], rh[2], rl[0]}; kl[b] = rl; vh[b] = kh[b];
+                vl[b] = u32x4{__builtin_bit_cast(unsigned, gav[b].x + gbv[b].y), rl[1], rl[2], rh[0]};
+            }
+        }
         SM_TICK(a.stamps, 3);
         // ---- key phase: k -> logits -> softmax over the atom's neighbour slots.  The bias of the key MLP's second Linear
         //      adds the same q_i . b2 to every neighbour's logit of a head and cancels in the softmax: it is not applied.
         float alpha[NT / 2];
-        {
+        if (SM_ABL(19)) {
+#pragma unroll
+            for (int t = 0; t < NT / 2; ++t) alpha[t] = qv[t].x * __builtin_bit_cast(float, kh[t][0] & 0x3fffffffu);
+        } else {
             f32x4 ka = tile_f16x3<NT, NT>(w2k, 0, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
             f32x4 kb = tile_f16x3<NT, NT>(w2k, NT / 2, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
 #pragma unroll
@@ -274,7 +297,8 @@ edge16_kernel(Edge16Args a) {
                 float *op = a.out + (size_t)atom * H;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const f32x4 v = tile_f16x3<NT, NT>(w2v, t, vh, vl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+                    const f32x4 v = SM_ABL(20) ? f32x4{__builtin_bit_cast(float, vh[t % (NT / 2)][0] & 0x3fffffffu), 1.f, 2.f, 3.f}
+                                               : tile_f16x3<NT, NT>(w2v, t, vh, vl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
                     const float4 bb = ldg4(b2 + 16 * t + 4 * g);
                     const float aw = al[t];
                     const float sw = seg_sum<SEGW>(aw);
@@ -472,9 +496,9 @@ edge16x2_kernel(Edge16Args a) {
         split_act16<NT>(hid, bh, bl);
     };
 
+    if (job0 < njobs) { locate(job0, 0); locate(job0, 1); request(0); }       // gathers before the image DMA (see edge16_kernel)
     dma_to_lds(lds, a.image_k, IMK::TOTAL / 4, wave, nwave, lane);
     dma_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, wave, nwave, lane);
-    if (job0 < njobs) { locate(job0, 0); locate(job0, 1); request(0); }
     __syncthreads();
 
     const float *imk = lds, *imv = lds + V_BASE;

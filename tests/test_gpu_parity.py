@@ -580,9 +580,10 @@ def test_chain_k32_b64_s20_golden():
     assert errs["pos_end"] < POS_TOL and errs["pos_snapshots"] < POS_TOL, errs
 
 
-@pytest.mark.parametrize("tiles", [1, 2])
+@pytest.mark.parametrize("tiles", [0, 1, 2])
 def test_forward_b1024_edge_tile_variants(tiles):
-    """Both multi-job instantiations of the f16 edge kernels (one / two 16-column tiles per wave-job) at B = 1024."""
+    """The three multi-job forms of the f16 edge kernels at B = 1024: sliced launches of the one-job kernel (default), one
+    looping launch with one / two 16-column tiles per wave-job."""
     m = hip_model()
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(1024, seed=14, max_atoms=38)
@@ -593,7 +594,7 @@ def test_forward_b1024_edge_tile_variants(tiles):
         with torch.no_grad():
             out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
     finally:
-        m.set_option("edge_tiles", 2)
+        m.set_option("edge_tiles", 0)
     for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
         assert maxabs(out[k], ref[k]) < FWD_TOL, k
 
