@@ -121,8 +121,9 @@ int shapemol_guide_points(shapemol_ctx *ctx, float *d_pos, int64_t n_points, con
  * out-of-range d_batch, an atom type outside [0, num_classes) or a time step outside [0, num_timesteps)
  * sets a sticky flag (the offending index is clamped, so nothing is read or written out of bounds).
  * shapemol_status synchronises the device and returns non-zero (message in shapemol_last_error) if the
- * last _score/_sample on this context saw such an input or a timed-out grid barrier (vn_fuse = 1);
- * flags_out (may be NULL) receives the eight raw flags {barrier, batch, atom type, time step, 0...}.
+ * last _score/_sample on this context saw such an input, an activation beyond the fp16 range of the two-piece f16 node
+ * kernels (option node_f16) or a timed-out grid barrier (vn_fuse = 1);
+ * flags_out (may be NULL) receives the eight raw flags {barrier, batch, atom type, time step, fp16 range, 0...}.
  * The reference raises from the corresponding torch indexing ops (models/molopt_score_model.py:292-301). */
 int shapemol_status(shapemol_ctx *ctx, int32_t *flags_out);
 
@@ -156,8 +157,14 @@ int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_sh
  *                        1 = fused kernel on exactly split bf16 operands (six products, weight swap between the phases),
  *                        2 = the same arithmetic as separate key / value launches, 0 = fp32-MFMA edge kernels;
  *                        k > 16 always uses the fp32 kernels),
- *          "lin_bf16", "chain_bf16" (1 = node kernels on the bf16 matrix cores with exactly split operands
- *                        [default], 0 = fp32-MFMA node kernels),
+ *          "node_f16"   (1 = node kernels (prologue, chain, per-node products) on two-piece f16 operands [default]: the
+ *                        residual stream then passes through fp16 pieces, |x| >= 6e4 raises a status flag;
+ *                        0 = the same kernels on exactly split bf16 operands, six products per term),
+ *          "lin_bf16", "chain_bf16" (1 = node kernels on the matrix cores with split operands [default],
+ *                        0 = fp32-MFMA node kernels),
+ *          "edge_tiles" (f16 edge kernels when the waves have several jobs (batches beyond ~6k atoms): 0 = sliced launches
+ *                        of the one-job kernel [default], 1 = one looping launch, 2 = one looping launch with two
+ *                        16-column tiles per wave-job; k > 16 always uses the two-tile kernel),
  *          "vn_fuse"    (2 = VN-linear + batch-norm statistics in the epilogue of the h2x attention, vn_apply as its
  *                        own launch [default]; 1 = the whole coordinate update behind h2x with an in-kernel grid
  *                        barrier (no faster: measured); 0 = separate vn_stats / vn_apply launches),

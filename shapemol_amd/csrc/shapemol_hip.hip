@@ -8,6 +8,7 @@
 #include "sm_edge_bf16.h"
 #include "sm_edge16.h"
 #include "sm_node.h"
+#include "sm_node16.h"
 #include "sm_misc.h"
 #include <hip/hip_ext.h>
 
@@ -116,11 +117,12 @@ struct Image {
 };
 
 struct DevMlp { size_t w1, b1, g, be, w2, b2; };            // raw row-major (VALU kernels)
-struct DevMlpImg { size_t w1img, b1, g, be, w2img, b2; int nt2; size_t w1img6, w2img6; };   // MFMA A-fragment images (sm_node.h)
+struct DevMlpImg { size_t w1img, b1, g, be, w2img, b2; int nt2; size_t w1img6, w2img6, w1img16, w2img16; };   // MFMA A-fragment images (sm_node.h)
 struct DevLayer {
     size_t pre_x2h, pre_h2x;          // images of [4H][H]: first-layer node blocks (k_i, k_j, v_i, v_j)
     size_t lin_img;                   // image of [8H][H]: pre_h2x of this layer followed by pre_x2h of the next
     size_t lin6_img, pre6_x2h;        // the same (and pre_x2h alone) as split bf16 images (node_linear6_kernel)
+    size_t lin16_img, pre16_x2h;      // ... and as two-piece f16 images (node_linear16_kernel)
     size_t sk_x2h, sv_x2h, sk_h2x, sv_h2x;   // [H][SL] shape columns of the first layers
     size_t bk_x2h, bv_x2h, bk_h2x, bv_h2x;   // first-layer biases [H]
     DevMlpImg q_x2h, q_h2x, no;
@@ -158,6 +160,7 @@ size_t put_padded(Image &im, const float *src, int n, int n_pad) {
 }
 void split3_host(float w, uint16_t (&p)[3]);
 size_t pack_linear6_image(Image &im, size_t src, int rows, int K);
+size_t pack_linear16_image(Image &im, size_t src, int rows, int K);
 DevMlpImg put_mlp_img(Image &im, const Mlp &m) {
     DevMlpImg d;
     const int r2 = (m.l2.out + 15) / 16 * 16;
@@ -169,6 +172,8 @@ DevMlpImg put_mlp_img(Image &im, const Mlp &m) {
     d.nt2 = r2 / 16;
     d.w1img6 = pack_linear6_image(im, d.w1img, m.l1.out, m.l1.in);
     d.w2img6 = pack_linear6_image(im, d.w2img, r2, m.l2.in);
+    d.w1img16 = pack_linear16_image(im, d.w1img, m.l1.out, m.l1.in);
+    d.w2img16 = pack_linear16_image(im, d.w2img, r2, m.l2.in);
     return d;
 }
 
@@ -349,6 +354,27 @@ size_t pack_linear6_image(Image &im, size_t src, int rows, int K) {
     return o;
 }
 
+// fp32 A-fragment image -> two-piece f16 image of node_linear16_kernel / node_chain16_kernel:
+//   [(((ot * 2 + piece) * NB + b) * 64 + lane) * 4 + q] u32
+size_t pack_linear16_image(Image &im, size_t src, int rows, int K) {
+    const int ntk = K / 16, NB = K / 32, nto = rows / 16;
+    const size_t o = im.alloc((size_t)nto * 2 * NB * 256);
+    uint32_t *w = reinterpret_cast<uint32_t *>(&im.d[o]);
+    for (int ot = 0; ot < nto; ++ot)
+        for (int b = 0; b < NB; ++b)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int q = 0; q < 4; ++q) {
+                    uint16_t pc[2][2];
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * q + e, t = 2 * b + (j >> 2), r = j & 3;
+                        split2_host(im.d[src + ((size_t)(ot * ntk + t) * 64 + lane) * 4 + r], pc[e]);
+                    }
+                    for (int piece = 0; piece < 2; ++piece)
+                        w[(((size_t)(ot * 2 + piece) * NB + b) * 64 + lane) * 4 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+                }
+    return o;
+}
+
 template <int H>
 int build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D, float &hid_max) {
     const int G = c.num_r_gaussian, SL = c.shape_latent_dim, S = c.shape_dim, hd = c.n_heads;
@@ -440,6 +466,7 @@ struct shapemol_ctx {
     const float *last_h = nullptr, *last_x = nullptr;
     // options
     int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 3, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
+    int node_f16 = 1;           // node kernels on two-piece f16 operands (sm_node16.h) instead of exactly split bf16 (sm_node.h)
     int edge_tiles = 0;         // f16 edge kernels when the waves have several jobs: 0 = sliced launches of the one-job kernel [default],
                                 // 1 = one looping launch (one tile per wave-job), 2 = one looping launch, two tiles per wave-job (8 waves)
     float hid_max = 0.f;        // bound of the edge MLPs' hidden activations (LayerNorm outputs): must fit fp16 for edge_bf16 = 3
@@ -542,6 +569,9 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)node_prologue6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * Chain6Lds<H>::FRAG * 16 + Chain6Lds<H>::PRE * 4)));
     HIPCHK(hipFuncSetAttribute((const void *)node_chain6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain6Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear6_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin6Chunk * 3 * H * 32));
+    HIPCHK(hipFuncSetAttribute((const void *)node_prologue16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * Chain16Lds<H>::FRAG * 16 + Chain16Lds<H>::PRE * 4)));
+    HIPCHK(hipFuncSetAttribute((const void *)node_chain16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain16Lds<H>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)node_linear16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin16Chunk * 2 * H * 32));
 #define SETATTR4(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
@@ -665,15 +695,19 @@ int launch_mlp2(shapemol_ctx *c, hipStream_t s, const char *name, const DevMlpIm
 }
 
 template <int H>
-int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float *in, const float *wimg, const float *wimg6, const float *add_mol,
+int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float *in, const float *wimg, const float *wimg6, const float *wimg16, const float *add_mol,
                   int ld_add, float *out, int ld_out, int n_out_tiles, int n_atoms, unsigned long long *stamps) {
     const int nwave = c->lin_waves;
     const int n_ct = (n_atoms + 15) / 16, ogroups = (n_out_tiles + nwave - 1) / nwave;
     const int want_groups = std::max(1, c->num_cu / ogroups);
     const int tpg = std::max(1, (n_ct + want_groups - 1) / want_groups);
     const int agroups = (n_ct + tpg - 1) / tpg;
-    NodeLinArgs a{in, c->lin_bf16 ? wimg6 : wimg, add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps};
-    if (c->lin_bf16) {
+    const bool f16 = c->lin_bf16 && c->node_f16;
+    NodeLinArgs a{in, f16 ? wimg16 : (c->lin_bf16 ? wimg6 : wimg), add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps};
+    if (f16) {
+        const size_t shm = (size_t)std::min(tpg, kLin16Chunk) * 2 * H * 32;
+        LAUNCH(name, SMK(node_linear16_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a, c->status + ST_RANGE));
+    } else if (c->lin_bf16) {
         const size_t shm = (size_t)std::min(tpg, kLin6Chunk) * 3 * H * 32;
         LAUNCH(name, SMK(node_linear6_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a));
     } else {
@@ -685,7 +719,7 @@ int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float 
 NodeFollow follow_of(const shapemol_ctx *c, const DevMlpImg &m, int mode, float *out, int ld_out, int n_store) {
     NodeFollow f{};
     f.w1img = c->P(m.w1img); f.b1 = c->P(m.b1); f.ln_g = c->P(m.g); f.ln_b = c->P(m.be);
-    f.w1img6 = c->P(m.w1img6); f.w2img6 = c->P(m.w2img6);
+    f.w1img6 = c->P(c->node_f16 ? m.w1img16 : m.w1img6); f.w2img6 = c->P(c->node_f16 ? m.w2img16 : m.w2img6);
     f.w2img = c->P(m.w2img); f.b2 = c->P(m.b2); f.out = out; f.ld_out = ld_out; f.n_store = n_store; f.mode = mode; f.nt2 = m.nt2;
     return f;
 }
@@ -738,11 +772,13 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         pa.emb_wT = c->P(c->dm.embwT); pa.emb_b = ae.b; pa.v = v_in; pa.mol_of = c->mol_of; pa.ttab = c->ttab; pa.t_mol = c->t_mol;
         pa.step_ptr = ae.step_ptr; pa.step_cur = ae.step_cur; pa.bn_acc = c->bn_acc; pa.h_out = c->h_a;
         pa.q = follow_of(c, D0.q_x2h, NODE_LN_RELU, c->q_x, H, H);
-        pa.lin_img6 = c->P(D0.pre6_x2h); pa.add_mol = c->add0; pa.pre_out = c->pre0;
+        pa.lin_img6 = c->P(c->node_f16 ? D0.pre16_x2h : D0.pre6_x2h); pa.add_mol = c->add0; pa.pre_out = c->pre0;
         pa.n_lin_tiles = nlay > 0 ? 4 * (H / 16) : 0; pa.ld_add = 4 * H; pa.ld_out = 4 * H;
         pa.n_atoms = n; pa.C = C; pa.D = D; pa.t_first = t_first; pa.bn_acc_len = ae.bn_acc_len;
         const int n_ct = (n + 15) / 16;
-        LAUNCH("node_prologue", SMK(node_prologue6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
+        if (c->node_f16) LAUNCH("node_prologue", SMK(node_prologue16_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
+                                                   2 * Chain16Lds<H>::FRAG * 16 + Chain16Lds<H>::PRE * 4, s, pa, c->status + ST_RANGE));
+        else LAUNCH("node_prologue", SMK(node_prologue6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
                                                    2 * Chain6Lds<H>::FRAG * 16 + Chain6Lds<H>::PRE * 4, s, pa));
     } else {
         LAUNCH("embed", SMK(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
@@ -760,7 +796,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     bool v_done = false;
     if (nlay > 0 && !fused_prologue) {   // prologue: per-node products and queries of the first x2h attention
         const DevLayer &D0 = c->dm.layer[0];
-        if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(D0.pre_x2h), c->P(D0.pre6_x2h), c->add0, 4 * H, c->pre0, 4 * H, 4 * NT, n,
+        if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(D0.pre_x2h), c->P(D0.pre6_x2h), c->P(D0.pre16_x2h), c->add0, 4 * H, c->pre0, 4 * H, 4 * NT, n,
                              c->kstamp_sel == 0 ? c->kstamps : nullptr)) return 1;
         if (launch_mlp2<H, 1>(c, s, "node_q", D0.q_x2h, cur_h, nullptr, NODE_LN_RELU, nullptr, c->q_x, H, H, n)) return 1;
     }
@@ -798,17 +834,18 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             na.stamps = (c->kstamp_sel == 3 && l == 0) ? c->kstamps : nullptr;
             na.w1img = c->P(Dl.no.w1img); na.b1 = c->P(Dl.no.b1); na.ln_g = c->P(Dl.no.g); na.ln_b = c->P(Dl.no.be);
             na.w2img = c->P(Dl.no.w2img); na.b2 = c->P(Dl.no.b2);
-            na.w1img6 = c->P(Dl.no.w1img6); na.w2img6 = c->P(Dl.no.w2img6);
+            na.w1img6 = c->P(c->node_f16 ? Dl.no.w1img16 : Dl.no.w1img6); na.w2img6 = c->P(c->node_f16 ? Dl.no.w2img16 : Dl.no.w2img6);
             na.f[0] = follow_of(c, Dl.q_h2x, NODE_LN_RELU, c->q_h, H, H);
             na.n_follow = 1;
             if (has_next) { na.f[1] = follow_of(c, c->dm.layer[l + 1].q_x2h, NODE_LN_RELU, c->q_x, H, H); na.n_follow = 2; }
             else if (out_v) { na.f[1] = follow_of(c, c->dm.vhead, NODE_SSP, out_v, C, C); na.n_follow = 2; v_done = true; }
             const int n_ct = (n + 15) / 16;
-            if (c->chain_bf16) LAUNCH("node_chain", SMK(node_chain6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain6Lds<H>::BYTES, s, na));
+            if (c->chain_bf16 && c->node_f16) LAUNCH("node_chain", SMK(node_chain16_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain16Lds<H>::BYTES, s, na, c->status + ST_RANGE));
+            else if (c->chain_bf16) LAUNCH("node_chain", SMK(node_chain6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain6Lds<H>::BYTES, s, na));
             else LAUNCH("node_chain", SMK(node_chain_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), 0, s, na));
             cur_h = dst;
             // per-node halves of the edge MLPs' first Linear: h2x of this layer | x2h of the next one
-            if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->P(Dl.lin6_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
+            if (launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->P(Dl.lin6_img), c->P(Dl.lin16_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
                                  c->preAB, 8 * H, (has_next && l + 1 < L ? 8 : 4) * NT, n, nullptr)) return 1;
         }
         float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
@@ -961,6 +998,8 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
     for (int l = 0; l < cfg->num_layers; ++l) {
         dm.layer[l].lin6_img = pack_linear6_image(im, dm.layer[l].lin_img, 8 * H, H);
         dm.layer[l].pre6_x2h = l == 0 ? pack_linear6_image(im, dm.layer[l].pre_x2h, 4 * H, H) : 0;
+        dm.layer[l].lin16_img = pack_linear16_image(im, dm.layer[l].lin_img, 8 * H, H);
+        dm.layer[l].pre16_x2h = l == 0 ? pack_linear16_image(im, dm.layer[l].pre_x2h, 4 * H, H) : 0;
     }
     im.alloc(64);
     if (hipMalloc((void **)&c->d_img, im.d.size() * sizeof(float)) != hipSuccess) { delete c; return fail("hipMalloc(weights) failed"); }
@@ -1107,6 +1146,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
         c->edge_bf16 = (int)value;
     }
     else if (k == "edge_tiles") { if (value < 0 || value > 2) return fail("edge_tiles must be 0, 1 or 2"); c->edge_tiles = (int)value; }
+    else if (k == "node_f16") c->node_f16 = value != 0;
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "chain_bf16") c->chain_bf16 = (int)value;
     else if (k == "vn_fuse") c->vn_fuse = (int)value;
@@ -1187,6 +1227,7 @@ int shapemol_status(shapemol_ctx *c, int32_t *flags_out) {
     if (f[ST_BATCH]) return fail("batch vector is not sorted ascending or names a molecule >= n_mols; results are invalid");
     if (f[ST_ATOM_TYPE]) return fail("an atom type is outside [0, num_classes); results are invalid");
     if (f[ST_TIME]) return fail("a time step is outside [0, num_timesteps); results are invalid");
+    if (f[ST_RANGE]) return fail("an activation left the fp16 range of the two-piece f16 node kernels (|x| >= 6e4 or NaN); results are invalid: set option node_f16 = 0 (exactly split bf16 kernels)");
     if (f[ST_VN_BARRIER]) return fail("grid barrier of the fused coordinate update timed out (workgroups not co-resident); results are invalid");
     return 0;
 }

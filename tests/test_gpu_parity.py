@@ -70,8 +70,9 @@ def test_forward_b4_golden(name):
         assert maxabs(out[k], f[f"{name}_{k}"]) < FWD_TOL, k
 
 
-@pytest.mark.parametrize("opts", [{"edge_bf16": 0}, {"edge_bf16": 1}, {"edge_bf16": 2}, {"lin_bf16": 0, "chain_bf16": 0}, {"vn_fuse": 1}, {"vn_fuse": 0}],
-                         ids=["edge_fp32", "edge_bf16x6", "edge_phases", "node_fp32", "vn_grid_barrier", "vn_separate"])
+@pytest.mark.parametrize("opts", [{"edge_bf16": 0}, {"edge_bf16": 1}, {"edge_bf16": 2}, {"lin_bf16": 0, "chain_bf16": 0}, {"node_f16": 0},
+                                  {"edge_bf16": 1, "node_f16": 0}, {"vn_fuse": 1}, {"vn_fuse": 0}],
+                         ids=["edge_fp32", "edge_bf16x6", "edge_phases", "node_fp32", "node_bf16x6", "all_exact_bf16x6", "vn_grid_barrier", "vn_separate"])
 def test_forward_alternative_kernels_golden(opts):
     """The optional kernel variants behind shapemol_set_option compute the same forward (ragged batch too)."""
     m = hip_model()
@@ -89,7 +90,7 @@ def test_forward_alternative_kernels_golden(opts):
         assert int(m.debug_read("vn_err", (1,), np.int32)[0]) == 0
     finally:
         for k in opts:
-            m.set_option(k, {"edge_bf16": 3, "lin_bf16": 1, "chain_bf16": 1, "vn_fuse": 2}[k])
+            m.set_option(k, {"edge_bf16": 3, "lin_bf16": 1, "chain_bf16": 1, "vn_fuse": 2, "node_f16": 1}[k])
 
 
 def test_forward_ragged_golden():
@@ -684,3 +685,29 @@ def test_shape_encoder_equivariance_and_oracle():
     sd = {k: torch.from_numpy(v) for k, v in synth.shape_encoder_state_dict(128, 32, 4, int(f["seed"])).items()}
     ref = SE.encode(sd, torch.from_numpy(pts), 4, 20).numpy()
     assert np.abs(z - ref).max() < 2e-5
+
+
+def test_fp16_range_guard_of_the_node_kernels():
+    """The two-piece f16 node kernels carry the residual stream in fp16 pieces: weights that drive it beyond 6e4 must be
+    reported (status flag -> exception), not silently turned into infinities; the exactly split bf16 kernels take them."""
+    import shapemol_amd
+    from shapemol_amd import _lib
+    from util import model_cfg
+    cfg = model_cfg()
+    sdn = synth.synthetic_state_dict(cfg, seed=7)
+    key = [k for k in sdn if k.endswith("ligand_atom_emb.weight")][0]
+    sdn[key] = sdn[key] * np.float32(3e5)
+    m = shapemol_amd.ScorePosNet3D(cfg, 15)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+    m = m.to(DEV)
+    bb = synth.synthetic_batch(4, seed=3)
+    args = (T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(np.full(4, 10, np.int64), DEV))
+    with torch.no_grad():
+        m(*args)
+    with pytest.raises(_lib.ShapeMolLibraryError, match="fp16 range"):
+        m.check_status()
+    m.set_option("node_f16", 0)
+    with torch.no_grad():
+        out = m(*args)
+    m.check_status()
+    assert torch.isfinite(out["pred_ligand_h"]).all()
