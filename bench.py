@@ -180,8 +180,8 @@ def main():
                    "noise": "device Philox", "trajectories": "kept in HBM" if not args.no_traj else "off",
                    "launch": "hipGraph replay" if use_graph else "eager", "parallelism": f"dp{world} (whole batches per rank)",
                    "ranks_seen": (dist.get_world_size() if dist is not None else 1), "ms_per_step_by_rank": rank_ms,
-                   "matrix_products": "edge MLPs: two-piece f16 operands (22 bits), fp32 accumulate; node MLPs: exactly split "
-                                      "bf16 operands (24 bits), fp32 accumulate; everything else fp32"},
+                   "matrix_products": "edge and node MLPs: two-piece f16 operands (22 significand bits), three products per term, fp32 "
+                                      "accumulate; everything else fp32 (options edge_bf16 = 1, node_f16 = 0: exactly split bf16 operands)"},
     }
 
     log(f"timed region done: {elapsed:.3f} s, {value:.2f} molecules/s")
@@ -215,11 +215,15 @@ def main():
         # matrix instructions the dominant kernel really issues (f16 or bf16 piece products), against the 2.5 PFLOP/s peak
         pieces = {"edge_x2h": 3 * 2 * (2 * HH + 2 * 32 * dm.H) * dm.k * n_atoms,
                   "edge_h2x": 3 * 2 * ((HH + 32 * dm.H) + (16 * dm.H + 32 * dm.H)) * dm.k * n_atoms,
-                  "node_chain": 6 * 14 * HH * n_atoms, "node_pre": 6 * 16 * HH * n_atoms}.get(dom)
+                  "node_chain": 3 * 14 * HH * n_atoms, "node_pre": 3 * 16 * HH * n_atoms}.get(dom)
         step_exec = f_exec_total * n_atoms / sec_per_step / 1e12
+        # ceiling of the formulation the kernel runs: every fp32 product is three f16 (edge, node) piece products on the
+        # f16 matrix cores, so the algorithm's fp32 FLOPs are bounded by the dense f16 peak / 3
+        peak_equiv = F16_MFMA_PEAK_TFLOPS / 3.0
         out["roofline"] = {
-            "bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": round(peak_equiv, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak_equiv, 4), "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
             "hbm_frac": (round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
             "matrix_pipe_frac": (round(pieces / avg_s / 1e12 / F16_MFMA_PEAK_TFLOPS, 4) if pieces else None),
             "step_frac": round(step_exec / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -228,7 +232,9 @@ def main():
             "timing": "begin/end timestamps of the kernel dispatches (hipExtLaunchKernelGGL start/stop events), eager pass "
                       f"of {max(1, args.profile_steps)} steps right after the timed region; rocprofv3 --kernel-trace --stats of the "
                       f"same command: profiles/{PROFILE_DIR}/kernel_stats.csv",
-            "note": "achieved/peak: fp32 FLOPs of the kernel's algorithm (factorised first Linears) against the dense fp32 MFMA peak. "
+            "note": "achieved: fp32 FLOPs of the kernel's algorithm (factorised first Linears) per second; peak: the dense f16 MFMA peak "
+                    "(2.5 PFLOP/s) / 3, because each fp32 product is evaluated as three f16 piece products (22-bit operands, fp32 "
+                    "accumulate) -- frac_of_fp32_mfma_peak compares the same rate with the 157.3 TFLOP/s fp32 matrix peak it no longer uses. "
                     "The step is latency-bound (about 44 dependent launches of 5-20 us on 5.5k atoms), not bound by either roof: "
                     "hbm_frac = PMC HBM bytes per launch / launch time / 8 TB/s, matrix_pipe_frac = f16/bf16 piece-product FLOPs "
                     "actually issued / 2.5 PFLOP/s, step_frac = executed fp32 FLOPs of the whole step / step time / fp32 peak",

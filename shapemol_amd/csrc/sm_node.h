@@ -307,6 +307,12 @@ struct NodeChainArgs {
     NodeFollow f[2];
     int n_follow, n_atoms;
     unsigned long long *stamps;   // diagnostic build only
+    // node_chain16_kernel only: the per-node products of the NEXT attentions (out[N][n_lin_tiles * 16] = h' W^T + per-molecule
+    // term) as a last use of the h' fragments, instead of a separate node_linear launch (n_lin_tiles = 0: none)
+    const float *lin_img16, *add_mol;
+    const int *mol_of;
+    float *pre_out;
+    int n_lin_tiles, ld_add, ld_out;
 };
 
 // One workgroup = NT waves (one per 16-row block of output features) x CHAIN_COLS column tiles: every weight

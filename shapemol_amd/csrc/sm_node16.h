@@ -265,6 +265,33 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
         N16::store_pre(pre1, acc, n, f0);
     }
     if (on1) N16::template load_w<NB>(a.f[1].w2img6, ot, lane, wg1);
+    // per-node products of the next attentions: tiles ot, ot + NT, ... of [n_lin_tiles * 16][H], weights alternating between
+    // two register sets so that the next block is in flight during the current product (as node_prologue16_kernel)
+    if (a.n_lin_tiles > 0) {
+        u32x4 wl[2][NB];
+        N16::template load_w<NB>(a.lin_img16, ot, lane, wl);
+        auto lin_tile = [&](int tile, const u32x4 (&w)[2][NB]) {
+            f32x4 acc[CC];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float4 t = a.add_mol ? ldg4(a.add_mol + (size_t)a.mol_of[atom_of(c)] * a.ld_add + 16 * tile + 4 * g)
+                                           : float4{0.f, 0.f, 0.f, 0.f};
+                acc[c] = f32x4{t.x, t.y, t.z, t.w};
+            }
+            N16::template gemm<NB>(w, fh, acc, lane);
+#pragma unroll
+            for (int c = 0; c < CC; ++c)
+                if (atom_ok(c)) stg4(a.pre_out + (size_t)atom_of(c) * a.ld_out + 16 * tile + 4 * g, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
+        };
+        for (int tile = ot; tile < a.n_lin_tiles; tile += 2 * NT) {
+            u32x4 wn[2][NB];
+            const bool more1 = tile + NT < a.n_lin_tiles, more2 = tile + 2 * NT < a.n_lin_tiles;
+            if (more1) N16::template load_w<NB>(a.lin_img16, tile + NT, lane, wn);
+            lin_tile(tile, wl);
+            if (more2) N16::template load_w<NB>(a.lin_img16, tile + 2 * NT, lane, wl);
+            if (more1) lin_tile(tile + NT, wn);
+        }
+    }
     __syncthreads();
     N16::normalise(pre0, a.f[0].mode, a.f[0].ln_g, a.f[0].ln_b, fhid0, ot, lane, range_flag);
     if (a.n_follow > 1) N16::normalise(pre1, a.f[1].mode, a.f[1].ln_g, a.f[1].ln_b, fhid1, ot, lane, range_flag);

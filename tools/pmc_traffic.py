@@ -5,15 +5,15 @@ Counters are in KB per dispatch (summed over the XCDs by rocprofv3); mean per la
 import collections, csv, json, re, sys
 
 CLASSES = [("edge_fused_kernel", "false", "edge_x2h"), ("edge_fused_kernel", "true", "edge_h2x"),
-           ("node_chain6_kernel", "", "node_chain"), ("node_chain_kernel", "", "node_chain"),
-           ("node_linear6_kernel", "", "node_pre"), ("node_linear_kernel", "", "node_pre"),
-           ("node_prologue6_kernel", "", "node_prologue"), ("vn_stats_kernel", "", "vn_stats"),
+           ("node_chain16_kernel", "", "node_chain"), ("node_chain6_kernel", "", "node_chain"), ("node_chain_kernel", "", "node_chain"),
+           ("node_linear16_kernel", "", "node_pre"), ("node_linear6_kernel", "", "node_pre"), ("node_linear_kernel", "", "node_pre"),
+           ("node_prologue16_kernel", "", "node_prologue"), ("node_prologue6_kernel", "", "node_prologue"), ("vn_stats_kernel", "", "vn_stats"),
            ("vn_apply_kernel", "", "vn_apply"), ("knn_kernel", "", "knn"), ("edge_weight_kernel", "", "edge_weight"),
            ("ddpm_step", "", "ddpm")]
 
 
 def classify(name):
-    m = re.search(r"edge_fused_kernel<\d+, \d+, (false|true)", name)      # third template argument: H2X
+    m = re.search(r"edge(?:_fused|16|16x2)_kernel<\d+, \d+, (false|true)", name)      # third template argument: H2X
     if m:
         return "edge_h2x" if m.group(1) == "true" else "edge_x2h"
     for key, flag, cls in CLASSES:
@@ -42,7 +42,7 @@ def mean_per_class(path, counter):
 
 fetch, n = mean_per_class(sys.argv[1], "FETCH_SIZE")
 write, _ = mean_per_class(sys.argv[2], "WRITE_SIZE")
-out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches, B=256, 5541 atoms); mean per "
+out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches); mean per "
                 "launch; counters are in KB (x1024 = bytes). Per MI355X_MICROARCH.md the gfx950 FETCH_SIZE under-reports wide "
                 "coalesced reads by 2x; the gather pattern here is uncalibrated, so both the raw and the doubled figure are "
                 "given; hbm_bytes_per_launch = 2 x fetch + write.", "kernels": {}}
