@@ -675,7 +675,8 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
     }
     // two tiles per wave-job, eight waves per workgroup: several jobs per wave (large batches) and k > 16
     const int apj2 = KP == 32 ? 1 : 32 / KP;
-    const int njobs = (a.n_atoms + apj2 - 1) / apj2, waves = 8;
+    const int njobs = (a.n_atoms + apj2 - 1) / apj2;
+    const int waves = c->edge_threads > 0 ? std::min(8, c->edge_threads / 64) : 8;      // option edge_waves (sweeps); 8 = two per SIMD
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
     const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float) + (H2X ? 512 * 16 : 0);
     if (KP == 8) LAUNCH(nm, SMK((edge16x2_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));

@@ -82,6 +82,14 @@ SM_DEV void dma_to_lds(float *lds, const float *g, int n4, int wave, int nwave, 
         __builtin_amdgcn_global_load_lds((gbl_void *)(g + ((size_t)c * 64 + lane) * 4), (lds_void *)(lds + (size_t)c * 256), 16, 0, 0);
 }
 
+// The same for any length: whole 1 KB pieces by LDS-DMA, the tail (< 64 float4) by one plain load -> store per thread.
+SM_DEV void image_to_lds(float *lds, const float *g, int n4, int tid, int wave, int nwave, int lane) {
+    dma_to_lds(lds, g, n4, wave, nwave, lane);
+    const int done = (n4 / 64) * 64;
+    if (tid < n4 - done)
+        reinterpret_cast<float4 *>(lds)[done + tid] = reinterpret_cast<const float4 *>(g)[done + tid];
+}
+
 // ---- cross-lane helpers without LDS traffic ------------------------------------------------------
 // DPP row operations (within a 16-lane row) and the gfx950 permlane swaps (between rows); a
 // __shfl_xor would lower to ds_bpermute_b32 (LDS pipe, ~100+ cycles of latency each).

@@ -365,8 +365,9 @@ edge_fused_kernel(EdgeFusedArgs a) {
     bool have = job < njobs;
     SM_TICK(a.stamps, 0);
     if (have) issue_loads(job, 0, H);
-    if (!SM_ABL(8)) copy_to_lds(lds, a.image_k, IMK::TOTAL / 4, threadIdx.x, blockDim.x);
-    if constexpr (H2X) { if (!SM_ABL(9)) copy_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, threadIdx.x, blockDim.x); }
+    // (LDS-DMA since round 2: the unrolled copy loop degenerated to seven dependent rounds per image, see sm_device.h)
+    if (!SM_ABL(8)) image_to_lds(lds, a.image_k, IMK::TOTAL / 4, threadIdx.x, wave, nwave, lane);
+    if constexpr (H2X) { if (!SM_ABL(9)) image_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, threadIdx.x, wave, nwave, lane); }
     __syncthreads();
     SM_TICK(a.stamps, 1);
     if (SM_ABL(10)) have = false;
@@ -435,7 +436,7 @@ edge_fused_kernel(EdgeFusedArgs a) {
     if (have) issue_loads(job, 2 * H, 3 * H);
     __syncthreads();                         // key weights no longer needed; alpha stores of this wave drained
     if constexpr (!H2X) {
-        if (!SM_ABL(9)) copy_to_lds(lds, a.image_v, IMV::TOTAL / 4, threadIdx.x, blockDim.x);
+        if (!SM_ABL(9)) image_to_lds(lds, a.image_v, IMV::TOTAL / 4, threadIdx.x, wave, nwave, lane);
         __syncthreads();
     }
     SM_TICK(a.stamps, 7);
