@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="molecules per GPU (BASELINE config 2: 256)")
     ap.add_argument("--atoms", type=str, default="", help="lo,hi: uniform atom counts instead of the MOSES prior (configs[4]: 40,80)")
     ap.add_argument("--knn", type=int, default=0, help="override the model's k (configs[4]: 32)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                                                      "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--cpu-steps", type=int, default=20, help="reverse steps of the CPU oracle to time (0 = skip)")
     ap.add_argument("--no-traj", action="store_true", help="do not keep per-step trajectories")
@@ -104,12 +106,17 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()          # rehearsal: ranks share the GPUs that exist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     cfg = yaml.safe_load(open(TRAIN_YML))["model"]
     if args.knn:
@@ -150,10 +157,11 @@ def main():
     elapsed = time.perf_counter() - t0
     local_elapsed = elapsed
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        natoms_all = torch.tensor([n_atoms], dtype=torch.int64, device=dev)
+        natoms_all = torch.tensor([n_atoms], dtype=torch.int64, device=cdev)
         dist.all_reduce(natoms_all)
         total_atoms = int(natoms_all.item())
     else:
@@ -162,8 +170,8 @@ def main():
     value = args.batch * world / (CHAIN_STEPS * sec_per_step)
     rank_ms = None
     if dist is not None:       # per-rank step time (the spread shows stragglers; `value` uses the max)
-        mine = torch.tensor([local_elapsed / steps * 1e3], dtype=torch.float64, device=dev)
-        allr = torch.empty(world, dtype=torch.float64, device=dev)
+        mine = torch.tensor([local_elapsed / steps * 1e3], dtype=torch.float64, device=cdev)
+        allr = torch.empty(world, dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(allr, mine)
         rank_ms = [round(float(x), 4) for x in allr.cpu()]
 

@@ -154,9 +154,8 @@ int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_sh
  *                        Used by the windowed full-length parity test; the reference always starts at T-1),
  *          "stop_layer" (run only the first v layers of the next _score; -1 = all),
  *          "edge_bf16"  (3 = fused key/value edge kernel on two-piece f16 operands, both MLP images resident [default];
- *                        1 = fused kernel on exactly split bf16 operands (six products, weight swap between the phases),
- *                        2 = the same arithmetic as separate key / value launches, 0 = fp32-MFMA edge kernels;
- *                        k > 16 always uses the fp32 kernels),
+ *                        1 = fused kernel on exactly split bf16 operands (six products, weight swap between the phases;
+ *                        k <= 16), 0 = fp32-MFMA edge kernels),
  *          "node_f16"   (1 = node kernels (prologue, chain, per-node products) on two-piece f16 operands [default]: the
  *                        residual stream then passes through fp16 pieces, |x| >= 6e4 raises a status flag;
  *                        0 = the same kernels on exactly split bf16 operands, six products per term),

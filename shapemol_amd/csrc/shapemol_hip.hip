@@ -559,10 +559,6 @@ int set_edge_attr(int KP) {
 #define SETATTR(K)                                                                                                    \
     HIPCHK(hipFuncSetAttribute((const void *)edge_attention_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b0)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_attention_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b1));
-#define SETATTR2(K)                                                                                                   \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_K>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_VX>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge_phase_kernel<H, K, PH_VH>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, 1>::TOTAL * 4));
 #define SETATTR3(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_fused_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EdgePhaseImage<H, H / 16>::TOTAL * 4)); \
@@ -582,10 +578,9 @@ int set_edge_attr(int KP) {
 #define SETATTR5(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge16x2_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16x2_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + 512 * 16));
-    if (KP == 8) { SETATTR(8) SETATTR2(8) SETATTR3(8) SETATTR4(8) SETATTR5(8) } else if (KP == 16) { SETATTR(16) SETATTR2(16) SETATTR3(16) SETATTR4(16) SETATTR5(16) } else { SETATTR(32) SETATTR5(32) }
+    if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) SETATTR5(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) SETATTR5(16) } else { SETATTR(32) SETATTR5(32) }
 #undef SETATTR5
 #undef SETATTR4
-#undef SETATTR2
 #undef SETATTR3
 #undef SETATTR
     return 0;
@@ -610,17 +605,6 @@ int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {     // fp32
     if (KP == 8) LAUNCH(nm, SMK((edge_attention_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     else if (KP == 16) LAUNCH(nm, SMK((edge_attention_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     else LAUNCH(nm, SMK((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
-    return 0;
-}
-
-template <int H, int MODE>
-int launch_phase(shapemol_ctx *c, hipStream_t s, const char *nm, const EdgePhaseArgs &a) {
-    const int KP = c->KP, apj = 16 / KP;
-    const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
-    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
-    const size_t shm = EdgePhaseImage<H, (MODE == PH_VH ? 1 : H / 16)>::TOTAL * sizeof(float);
-    if (KP == 8) LAUNCH(nm, SMK((edge_phase_kernel<H, 8, MODE>), dim3(grid), dim3(waves * 64), shm, s, a));
-    else LAUNCH(nm, SMK((edge_phase_kernel<H, 16, MODE>), dim3(grid), dim3(waves * 64), shm, s, a));
     return 0;
 }
 
@@ -818,13 +802,6 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             EdgeFusedArgs fa{c->P(Dl.img_kx), c->P(Dl.img_vx), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew,
                              c->alpha, c->att, n, l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
             if (launch_fused<H, false>(c, s, fa)) return 1;
-        } else if (phases) {   // x2h attention: key phase -> alpha, value phase -> att (separate launches)
-            const float *pre = l == 0 ? c->pre0 : c->preAB + 4 * H;
-            const int ldp = l == 0 ? 4 * H : 8 * H;
-            EdgePhaseArgs pk{c->P(Dl.img_kx), pre, c->q_x, cur_x, c->nbr, c->ew, c->alpha, nullptr, n, ldp, 0, H};
-            if (launch_phase<H, PH_K>(c, s, "edge_x2h_k", pk)) return 1;
-            EdgePhaseArgs pv{c->P(Dl.img_vx), pre, nullptr, cur_x, c->nbr, c->ew, c->alpha, c->att, n, ldp, 2 * H, 3 * H};
-            if (launch_phase<H, PH_VX>(c, s, "edge_x2h_v", pv)) return 1;
         } else {   // x2h attention (fp32 MFMA kernels)
             EdgeArgs e{c->P(Dl.blob_x2h), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew, c->att, n,
                        l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
@@ -871,7 +848,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                 stats_done = true;
             }
             if (launch_edge16<H, true>(c, s, ea)) return 1;
-        } else if (phases && c->edge_bf16 != 2) {   // h2x attention, both images resident in LDS
+        } else if (phases) {   // h2x attention, both images resident in LDS (exactly split bf16 operands)
             EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H,
                              (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
             if (c->vn_fuse) {   // VN-linear + batch statistics (2) or the whole coordinate update (1: grid barrier inside) behind the attention
@@ -882,11 +859,6 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                 if (c->vn_fuse == 1) vn_done = true; else stats_done = true;
             }
             if (launch_fused<H, true>(c, s, fa)) return 1;
-        } else if (phases) {   // h2x attention (separate launches)
-            EdgePhaseArgs pk{c->P(Dl.img_kh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, nullptr, n, 8 * H, 0, H};
-            if (launch_phase<H, PH_K>(c, s, "edge_h2x_k", pk)) return 1;
-            EdgePhaseArgs pv{c->P(Dl.img_vh), c->preAB, nullptr, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H, 2 * H, 3 * H};
-            if (launch_phase<H, PH_VH>(c, s, "edge_h2x_v", pv)) return 1;
         } else {   // h2x attention (fp32 MFMA kernels)
             EdgeArgs e{c->P(Dl.blob_h2x), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->o3, n, 8 * H,
                        (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
@@ -1151,6 +1123,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     }
     if (k == "stop_layer") c->stop_layer = (int)value;
     else if (k == "edge_bf16") {
+        if (value != 0 && value != 1 && value != 3) return fail("edge_bf16 must be 0 (fp32 MFMA), 1 (exactly split bf16) or 3 (two-piece f16)");
         if (value == 3 && c->hid_max > 6.0e4f) return fail("edge_bf16 = 3: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights");
         c->edge_bf16 = (int)value;
     }

@@ -11,9 +11,9 @@
 //         key    : logits + per-atom softmax over the neighbour slots           -> alpha
 //         value x: x2h values, sum_j alpha * e_w * v_ij                          -> att [N][H]
 //         value h: h2x values (one per head), sum_j alpha * e_w * v_ij * rel_x   -> o3  [N][16][3]
-//   * edge_fused_kernel (default) runs both phases of an attention in one launch (image swap in LDS for x2h,
-//     both images resident for h2x) and, for h2x, the VN-linear + batch-norm statistics of the coordinate
-//     update in its epilogue; edge_phase_kernel runs one phase per launch (option edge_bf16 = 2).
+//   * edge_fused_kernel runs both phases of an attention in one launch (image swap in LDS for x2h, both images
+//     resident for h2x) and, for h2x, the VN-linear + batch-norm statistics of the coordinate update in its epilogue.
+//     (Since round 2 the default kernels are those of sm_edge16.h; these are option edge_bf16 = 1, the exactly split form.)
 // One job = the KP <= 16 neighbour slots of 16 / KP centre atoms = one 16-column tile, one job per wave where
 // the jobs fit; loads of a job are issued before the weight image is copied to LDS.
 #pragma once
@@ -24,20 +24,6 @@
 #ifndef SM_ABL
 #define SM_ABL(bit) (((SM_ABLATE) >> (bit)) & 1)
 #endif
-
-enum EdgePhase { PH_K = 0, PH_VX = 1, PH_VH = 2 };
-
-struct EdgePhaseArgs {
-    const float *image;     // packed weights of this MLP (EdgePhaseImage)
-    const float *pre;       // node pre-products, row stride ld_pre
-    const float *q;         // [N][H]            (PH_K)
-    const float *x;         // [N][3]
-    const int *nbr;         // [N][KP]
-    const float *ew;        // [N][KP]           (value phases)
-    float *alpha;           // [N*KP][2][NT]     written by PH_K, read by the value phases
-    float *out;             // PH_VX: [N][H]; PH_VH: [N][16][3]
-    int n_atoms, ld_pre, col_a, col_b;   // column offsets of the centre / neighbour product inside a pre row
-};
 
 // LDS image of ONE edge MLP, in 32-bit words
 template <int H, int NT2>
@@ -116,146 +102,6 @@ template <class IM, int NT>
 SM_DEV void first_linear_of(const float *img, const float (&rb)[5], f32x4 (&acc)[NT], int lane) {
     if constexpr (IM::BF1) first_linear_rbf_bf16<NT>(img + IM::O_WR, rb, acc, lane);
     else first_linear_rbf<NT>(img + IM::O_WR, rb, acc, lane);
-}
-
-template <int H, int KP, int MODE>
-__global__ void __launch_bounds__(768)
-edge_phase_kernel(EdgePhaseArgs a) {
-    static_assert(KP == 8 || KP == 16, "single-tile jobs");
-    constexpr int NT = H / 16;
-    constexpr int NT2 = MODE == PH_VH ? 1 : NT;
-    using IM = EdgePhaseImage<H, NT2>;
-    constexpr int APJ = 16 / KP, SEGW = KP;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int n = lane & 15, g = lane >> 4;
-    float cen[5];
-    rbf_centres(g, cen);
-    const int njobs = (a.n_atoms + APJ - 1) / APJ;
-    const int jstride = gridDim.x * nwave;
-
-    int job = blockIdx.x * nwave + wave;
-    bool have = job < njobs;
-    int atom = 0, jn = 0, edge = 0;
-    bool atom_ok = false, ok = false;
-    float xi[3], xj[3], ewv = 0.f;
-    float4 ga[NT], gb[NT];
-    float4 al4[2];                                     // attention weights of this lane's edge (value phases)
-
-    auto issue_loads = [&](int jb) {
-        const int atom_raw = jb * APJ + n / SEGW;
-        atom_ok = atom_raw < a.n_atoms;
-        atom = atom_ok ? atom_raw : a.n_atoms - 1;
-        edge = atom * KP + n % SEGW;
-        const int jraw = a.nbr[edge];
-        ok = atom_ok && jraw >= 0;
-        jn = ok ? jraw : atom;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { xi[k] = a.x[atom * 3 + k]; xj[k] = a.x[jn * 3 + k]; }
-        const float *pi = a.pre + (size_t)atom * a.ld_pre + a.col_a, *pj = a.pre + (size_t)jn * a.ld_pre + a.col_b;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { ga[t] = ldg4(pi + 16 * t + 4 * g); gb[t] = ldg4(pj + 16 * t + 4 * g); }
-        if constexpr (MODE != PH_K) {
-            ewv = a.ew[edge];
-            const float *ap = a.alpha + (size_t)edge * 2 * NT + (g >> 1) * NT;
-            if constexpr (MODE == PH_VX) {
-#pragma unroll
-                for (int i = 0; i < (NT + 3) / 4; ++i) al4[i] = ldg4(ap + 4 * i);
-            } else {
-                if constexpr (NT >= 8) al4[0] = ldg4(ap + (NT / 2) * (g & 1));
-                else { al4[0] = float4{0.f, 0.f, 0.f, 0.f}; al4[0].x = ap[(NT / 2) * (g & 1)]; }
-            }
-        }
-    };
-    if (have) issue_loads(job);
-    copy_to_lds(lds, a.image, IM::TOTAL / 4, threadIdx.x, blockDim.x);
-    __syncthreads();
-
-    const unsigned *w2 = reinterpret_cast<const unsigned *>(lds) + IM::O_W2;
-    while (have) {
-        asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
-        const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
-        const float d = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
-        float rb[5];
-        rbf_dlayout(d, cen, rb);
-        // first Linear (fp32 MFMA, K = 20) + LayerNorm + ReLU
-        float hid[NT * 4];
-        {
-            f32x4 acc[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
-            first_linear_of<IM, NT>(lds, rb, acc, lane);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
-                hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
-            }
-        }
-        ln_relu_dlayout<NT>(hid, lds + IM::O_G, lds + IM::O_B, g);
-        // second Linear on the bf16 matrix cores (six exact piece products)
-        f32x4 acc2[NT2];
-#pragma unroll
-        for (int t = 0; t < NT2; ++t) {
-            const float4 b2 = ldg4(lds + IM::O_B2 + 16 * t + 4 * g);
-            acc2[t] = f32x4{b2.x, b2.y, b2.z, b2.w};
-        }
-        gemm_bf16x6<NT, NT2>(w2, hid, acc2, lane);
-
-        const int cur_atom = atom, cur_edge = edge;
-        const bool cur_atom_ok = atom_ok, cur_ok = ok;
-        const float w = ok ? ewv : 0.f;
-        job += jstride;
-        have = job < njobs;
-        if constexpr (MODE == PH_K) {
-            f32x4 kk[NT2];
-#pragma unroll
-            for (int t = 0; t < NT2; ++t) kk[t] = acc2[t];
-            float alpha[NT / 2];
-            if constexpr (NT2 == NT) attention_weights<NT, SEGW>(a.q + (size_t)cur_atom * H, kk, cur_ok, g, alpha);
-            if (cur_atom_ok) {
-                float *ap = a.alpha + (size_t)cur_edge * 2 * NT + (g >> 1) * NT + (NT / 2) * (g & 1);
-#pragma unroll
-                for (int t = 0; t < NT / 2; ++t) ap[t] = alpha[t];
-            }
-            if (have) issue_loads(job);
-        } else if constexpr (MODE == PH_VX) {
-            const float al[8] = {al4[0].x, al4[0].y, al4[0].z, al4[0].w, al4[1].x, al4[1].y, al4[1].z, al4[1].w};
-            float o[NT * 4];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float aw = al[t % 8] * w;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[4 * t + r] = seg_sum<SEGW>(aw * acc2[t][r]);
-            }
-            if (cur_atom_ok && (n % SEGW) == 0) {
-                float *op = a.out + (size_t)cur_atom * H;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    stg4(op + 16 * t + 4 * g, float4{o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]});
-            }
-            if (have) issue_loads(job);
-        } else {
-            // value row 4g + r belongs to head 2*((NT/2)*(g&1) + r) + (g>>1): al4[0] holds exactly those
-            // alphas (rows with r >= NT/2 are zero padding)
-            const float al[4] = {al4[0].x, al4[0].y, al4[0].z, al4[0].w};
-            float o[12];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float av = r < NT / 2 ? al[r] * w * acc2[0][r] : 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) o[3 * r + k] = seg_sum<SEGW>(av * rel[k]);
-            }
-            if (cur_atom_ok && (n % SEGW) == 0) {
-                float *op = a.out + (size_t)cur_atom * 48 + 12 * g;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    stg4(op + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
-            }
-            if (have) issue_loads(job);
-        }
-    }
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -28,6 +28,9 @@ def gather_molecules(pos, v, counts, group=None):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return pos, v, counts
     ws = dist.get_world_size(group)
+    out_dev = pos.device
+    if dist.get_backend(group) == "gloo" and pos.is_cuda:      # rehearsals on one GPU (bench.py --backend gloo): collectives on the host
+        pos, v, counts = pos.cpu(), v.cpu(), counts.cpu()
     dev = pos.device
     n_r, b_r = int(pos.shape[0]), int(counts.shape[0])
     sizes = torch.tensor([n_r, b_r], dtype=torch.int64, device=dev)
@@ -48,4 +51,4 @@ def gather_molecules(pos, v, counts, group=None):
         out_p.append(gathered[r, :3 * nr].view(torch.float32).reshape(nr, 3))
         out_v.append(gathered[r, 3 * max_n:3 * max_n + nr].to(torch.int64))
         out_c.append(gathered[r, 4 * max_n:4 * max_n + br].to(torch.int64))
-    return torch.cat(out_p), torch.cat(out_v), torch.cat(out_c)
+    return torch.cat(out_p).to(out_dev), torch.cat(out_v).to(out_dev), torch.cat(out_c).to(out_dev)

@@ -37,6 +37,8 @@ class ChainRunner:
         self.stream = torch.cuda.Stream(device=self.dev)
         self.ctx = model._context(self.dev)
         _lib.check(_lib.load().shapemol_reserve(self.ctx, self.n, self.b), "shapemol_reserve")
+        # a library context owns ONE workspace: chains of the same model must not be in flight on two streams at once
+        model.__dict__.setdefault("_runners", []).append(self)
 
     def load_batch(self, init_pos, init_v, batch, shape):
         self.pos0.copy_(torch.as_tensor(init_pos)); self.v0.copy_(torch.as_tensor(init_v))
@@ -50,6 +52,10 @@ class ChainRunner:
     def run(self, num_steps, seed=0, use_graph=True):
         """Enqueue a chain of `num_steps` reverse steps on the runner's stream (no host sync)."""
         assert 1 <= num_steps <= self.max_steps
+        for other in self.model.__dict__.get("_runners", []):
+            if other is not self and not other.stream.query():
+                raise RuntimeError("another ChainRunner of the same model still has a chain in flight: a context has one workspace; "
+                                   "synchronize() it first, or give the second runner its own model (own context)")
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
         with torch.cuda.device(self.dev):
             rc = _lib.load().shapemol_sample(self.ctx, p(self.pos0), p(self.v0), p(self.batch), self.n, self.b, p(self.shape),
