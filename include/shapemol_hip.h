@@ -149,7 +149,8 @@ void shapemol_se_destroy(shapemol_se_ctx *ctx);
 int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_shapes, int64_t n_points, float *d_out, void *stream);
 
 /* ---- diagnostics (used by the parity tests and the bench; not needed by a caller) ---- */
-/* options: "first_step" (the following _sample calls resume a chain at reverse step v, i.e. at t = T-1-v, from the
+/* (options marked "_sample only" do not affect _score)
+ * options: "first_step" (the following _sample calls resume a chain at reverse step v, i.e. at t = T-1-v, from the
  *                        state given as d_init_pos / d_init_v; noise and trajectory rows stay indexed from 0; default 0.
  *                        Used by the windowed full-length parity test; the reference always starts at T-1),
  *          "stop_layer" (run only the first v layers of the next _score; -1 = all),
@@ -164,6 +165,12 @@ int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_sh
  *          "edge_tiles" (f16 edge kernels when the waves have several jobs (batches beyond ~6k atoms): 0 = sliced launches
  *                        of the one-job kernel [default], 1 = one looping launch, 2 = one looping launch with two
  *                        16-column tiles per wave-job; k > 16 always uses the two-tile kernel),
+ *          "max_mol_atoms" (_sample only: largest molecule, in atoms, of the batches of the following chains; 0 = unknown [default].  With it
+ *                        the coordinate update of every layer but the last runs in the prologue of the next layer's x2h
+ *                        kernel (each workgroup recomputes the coordinates of the molecules its atoms belong to) instead
+ *                        of as a launch of its own; a value smaller than the truth raises a status flag.  Does not touch the
+ *                        captured graph unless it changes that decision),
+ *          "vn_fold"    (1 = fold as above when max_mol_atoms allows [default], 0 = always launch vn_apply),
  *          "vn_fuse"    (2 = VN-linear + batch-norm statistics in the epilogue of the h2x attention, vn_apply as its
  *                        own launch [default]; 1 = the whole coordinate update behind h2x with an in-kernel grid
  *                        barrier (no faster: measured); 0 = separate vn_stats / vn_apply launches),

@@ -451,6 +451,7 @@ struct shapemol_ctx {
     int *mol_of = nullptr, *mol_off = nullptr, *t_mol = nullptr, *nbr = nullptr, *steps = nullptr;
     float *temb = nullptr, *inv = nullptr, *add0 = nullptr, *addp = nullptr, *ps = nullptr, *ew = nullptr;
     float *h_a = nullptr, *h_b = nullptr, *pre0 = nullptr, *preAB = nullptr, *q_x = nullptr, *q_h = nullptr, *att = nullptr, *o3 = nullptr, *pd = nullptr;
+    float *xsum = nullptr;      // [N][3] per-atom sum of the h2x attention rows (folded coordinate update)
     float *alpha = nullptr;     // [N*KP][2][NT] attention weights handed from the key phase to the value phase
     float *x_a = nullptr, *x_b = nullptr, *x_state = nullptr, *pred_pos = nullptr, *pred_v = nullptr;
     int64_t *v_state = nullptr;
@@ -466,6 +467,8 @@ struct shapemol_ctx {
     const float *last_h = nullptr, *last_x = nullptr;
     // options
     int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 3, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
+    int vn_fold = 1;            // coordinate update of layer l in the prologue of the x2h kernel of layer l + 1 (needs max_mol_atoms)
+    int max_mol_atoms = 0;      // largest molecule of the batches to come (option; 0 = unknown: no fold)
     int lin_fuse = 0;           // 1: per-node products of the next attentions inside node_chain16_kernel instead of a node_linear
                                 // launch (measured: 28.5 us against 15.3 + 11.1 us, eight dependent weight blocks per wave)
     int node_f16 = 1;           // node kernels on two-piece f16 operands (sm_node16.h) instead of exactly split bf16 (sm_node.h)
@@ -484,7 +487,7 @@ struct shapemol_ctx {
     hipGraphExec_t gexec = nullptr, gexec_u = nullptr;     // one step / kGraphUnroll steps
     int64_t n_captures = 0;                                // graph captures so far (debug_read "captures")
     // the captured step depends on the batch geometry only: seed, noise and trajectory pointers live in chain_params
-    struct GraphKey { int64_t N = 0, B = 0; int guided = 0; bool operator==(const GraphKey &o) const { return N == o.N && B == o.B && guided == o.guided; } } gkey{};
+    struct GraphKey { int64_t N = 0, B = 0; int guided = 0, fold = 0; bool operator==(const GraphKey &o) const { return N == o.N && B == o.B && guided == o.guided && fold == o.fold; } } gkey{};
     void drop_graphs() {      // a replay may still be in flight: drain the device before destroying the executables
         if (!gexec && !gexec_u) return;
         hipDeviceSynchronize();
@@ -544,13 +547,27 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
         A(&c->steps, 4) || A(&c->temb, capB * g.time_emb_dim) || A(&c->inv, capB * g.shape_latent_dim) ||
         A(&c->add0, (size_t)capB * 4 * H) || A(&c->addp, (size_t)L * capB * 8 * H) || A(&c->ps, (size_t)L * capB * 2 * hd * 3) || A(&c->ew, capN * c->KP) ||
         A(&c->h_a, capN * H) || A(&c->h_b, capN * H) || A(&c->pre0, capN * 4 * H) || A(&c->preAB, capN * 8 * H) || A(&c->q_x, capN * H) || A(&c->q_h, capN * H) ||
-        A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->alpha, capN * c->KP * 2 * (H / 16)) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
+        A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->xsum, capN * 3) || A(&c->alpha, capN * c->KP * 2 * (H / 16)) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
         A(&c->x_b, capN * 3) || A(&c->x_state, capN * 3) || A(&c->pred_pos, capN * 3) ||
         A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * kBnReplicas * 2 * hd + L + 1) ||
         A(&c->status, 8) || A(&c->chain_params, 1))
         return 1;
     c->capN = capN; c->capB = capB;
     return 0;
+}
+
+constexpr int kVnFoldBytes = kVnFoldCap * 3 * 4 + 32 * 8;      // LDS of the folded coordinate update: table + batch sums
+
+// can the coordinate update of a layer be folded into the next x2h kernel?  f16 one-job (or sliced) edge kernels, the
+// VN-linear + statistics epilogue in h2x, and every workgroup's molecule span inside the LDS table
+bool vn_fold_ok(const shapemol_ctx *c, int n_atoms) {
+    if (!c->vn_fold || c->edge_bf16 != 3 || c->KP > 16 || c->vn_fuse != 2 || c->max_mol_atoms <= 0) return false;
+    const int apj = 16 / c->KP, njobs = (n_atoms + apj - 1) / apj;
+    const int waves = std::max(4, std::min(12, (njobs + c->num_cu - 1) / c->num_cu));
+    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
+    if (c->edge_threads > 0) return false;                                 // wave-count sweeps: keep the plain path
+    if (njobs > grid * waves && c->edge_tiles != 0) return false;         // looping launches: a workgroup's jobs are not contiguous
+    return waves * apj + 2 * (c->max_mol_atoms - 1) <= kVnFoldCap;
 }
 
 template <int H>
@@ -571,8 +588,8 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)node_chain16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain16Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin16Chunk * 2 * H * 32));
 #define SETATTR4(K)                                                                                                   \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
 #define SETATTR5(K)                                                                                                   \
@@ -637,7 +654,7 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
         const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
         const bool one = njobs <= grid * waves;      // every wave has at most one job: straight-line instantiation
         const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
-                           + (H2X ? (size_t)vn_red_doubles(waves, H / 8) * 8 + (size_t)waves * apj * 48 * 4 : 0);
+                           + (H2X ? (size_t)vn_red_doubles(waves, H / 8) * 8 + (size_t)waves * apj * 48 * 4 : (a.vf.enable ? kVnFoldBytes : 0));
         if (one || c->edge_tiles == 0) {
             // larger batches (edge_tiles = 0): several launches of the straight-line instantiation, each over a slice of
             // grid x waves jobs (no spills, full overlap inside a launch; the image fill is paid per slice)
@@ -787,6 +804,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                              c->kstamp_sel == 0 ? c->kstamps : nullptr)) return 1;
         if (launch_mlp2<H, 1>(c, s, "node_q", D0.q_x2h, cur_h, nullptr, NODE_LN_RELU, nullptr, c->q_x, H, H, n)) return 1;
     }
+    const bool fold = sampling && vn_fold_ok(c, n);       // chains only: coordinate update of layer l inside the x2h kernel of layer l + 1
+    VnFold pending{};                         // ... which then receives this
     for (int l = 0; l < nlay; ++l) {
         const DevLayer &Dl = c->dm.layer[l];
         const bool last = (l == nlay - 1), has_next = !last;
@@ -797,6 +816,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             ea.image_k = c->P(Dl.i16_kx); ea.image_v = c->P(Dl.i16_vx);
             ea.pre = l == 0 ? c->pre0 : c->preAB + 4 * H; ea.q = c->q_x; ea.x = cur_x; ea.nbr = c->nbr; ea.ew = c->ew; ea.out = c->att;
             ea.n_atoms = n; ea.ld_pre = l == 0 ? 4 * H : 8 * H; ea.stamps = (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr;
+            ea.vf = pending; pending = VnFold{};
             if (launch_edge16<H, false>(c, s, ea)) return 1;
         } else if (phases && c->edge_bf16 == 1) {   // x2h attention, key and value phase in one launch
             EdgeFusedArgs fa{c->P(Dl.img_kx), c->P(Dl.img_vx), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew,
@@ -846,6 +866,12 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                          c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd,
                          nullptr, c->status + ST_VN_BARRIER, x_next, 2};
                 stats_done = true;
+                if (fold && has_next) {      // no vn_apply launch: the next x2h kernel finishes the update
+                    ea.xsum = c->xsum;
+                    pending = VnFold{c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, x_next,
+                                     c->mol_of, c->mol_off, c->status + ST_SPAN, 1};
+                    vn_done = true;
+                }
             }
             if (launch_edge16<H, true>(c, s, ea)) return 1;
         } else if (phases) {   // h2x attention, both images resident in LDS (exactly split bf16 operands)
@@ -1067,7 +1093,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
     };
     if (use_graph && !c->prof_on) {
         shapemol_ctx::GraphKey key{};
-        key.N = N; key.B = B; key.guided = c->g_points > 0;
+        key.N = N; key.B = B; key.guided = c->g_points > 0; key.fold = vn_fold_ok(c, (int)N);
         // two executables: one reverse step, and kGraphUnroll steps back to back (the gap between two graph launches,
         // ~5 us, is then paid once per kGraphUnroll steps); every step reads its index from the device-side counter
         auto capture = [&](int n_steps, hipGraphExec_t *exec) -> int {
@@ -1116,6 +1142,11 @@ int shapemol_log_sample_categorical(shapemol_ctx *c, const float *d_logits, cons
 int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail("shapemol_set_option: null argument");
     const std::string k(name);
+    if (k == "max_mol_atoms") {   // hint for the folded coordinate update; the captured graph is keyed on the resulting decision
+        if (value < 0) return fail("max_mol_atoms must be >= 0");
+        c->max_mol_atoms = (int)std::min<int64_t>(value, 1 << 20);
+        return 0;
+    }
     if (k == "first_step") {      // does not touch the captured graph: the step counter lives in device memory
         if (value < 0 || value >= c->cfg.num_timesteps) return fail("first_step must be in [0, num_timesteps)");
         c->first_step = (int)value;
@@ -1130,6 +1161,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     else if (k == "edge_tiles") { if (value < 0 || value > 2) return fail("edge_tiles must be 0, 1 or 2"); c->edge_tiles = (int)value; }
     else if (k == "node_f16") c->node_f16 = value != 0;
     else if (k == "lin_fuse") c->lin_fuse = value != 0;
+    else if (k == "vn_fold") c->vn_fold = value != 0;
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "chain_bf16") c->chain_bf16 = (int)value;
     else if (k == "vn_fuse") c->vn_fuse = (int)value;
@@ -1210,6 +1242,7 @@ int shapemol_status(shapemol_ctx *c, int32_t *flags_out) {
     if (f[ST_BATCH]) return fail("batch vector is not sorted ascending or names a molecule >= n_mols; results are invalid");
     if (f[ST_ATOM_TYPE]) return fail("an atom type is outside [0, num_classes); results are invalid");
     if (f[ST_TIME]) return fail("a time step is outside [0, num_timesteps); results are invalid");
+    if (f[ST_SPAN]) return fail("a molecule is larger than the max_mol_atoms hint allows for the folded coordinate update; results are invalid");
     if (f[ST_RANGE]) return fail("an activation left the fp16 range of the two-piece f16 node kernels (|x| >= 6e4 or NaN); results are invalid: set option node_f16 = 0 (exactly split bf16 kernels)");
     if (f[ST_VN_BARRIER]) return fail("grid barrier of the fused coordinate update timed out (workgroups not co-resident); results are invalid");
     return 0;

@@ -102,6 +102,24 @@ SM_DEV f32x4 tile_f16x3(const unsigned *w2, int t2, const u32x4 (&bh)[NT / 2], c
     return c;
 }
 
+// x2h only: the coordinate update of the PREVIOUS layer (vn_apply_kernel: batch-norm of ||p||, VN-leaky-ReLU, mean over the
+// channels, x += ...; uni_transformer.py:153-162, shape_vn_layers.py:41-61,95-110) folded into this kernel's prologue: the
+// workgroup recomputes the new coordinates of every atom of the molecules its jobs touch (their neighbours live there) into
+// an LDS table, from the p / d vectors and the batch sums the h2x kernel left behind, and writes those of its own atoms to
+// global memory for the kernels that follow.  Saves the vn_apply launch (5 us) of every layer but the last.
+constexpr int kVnFoldCap = 256;       // atoms of the LDS coordinate table (the host enables the fold only if every span fits)
+struct VnFold {
+    const float *pd;          // [N][heads][6]
+    const double *acc;        // [kVnReplicas][2][heads] batch sums of the previous layer
+    const float *bn_g, *bn_b; // [heads]
+    const float *xsum;        // [N][3] sum over the attention rows, written by the h2x epilogue
+    const float *x_old;       // [N][3]
+    float *x_new;             // [N][3]
+    const int *mol_of, *mol_off;
+    int *span_flag;           // status flag raised if a workgroup's molecule span exceeds the table
+    int enable;
+};
+
 struct Edge16Args {
     const float *image_k, *image_v;   // EdgeImage16 of the key / value MLP
     const float *pre;       // node pre-products [N][ld_pre]: A_k | B_k | A_v | B_v at column offsets 0, H, 2H, 3H
@@ -114,6 +132,8 @@ struct Edge16Args {
     int job_base, job_end;            // edge16_kernel: this launch covers jobs [job_base, job_end) (job_end = 0: all of them)
     unsigned long long *stamps;       // diagnostic build only
     EdgeFusedArgs::VnFuse vn;         // h2x: VN-linear + batch statistics behind the attention (enable = 0 or 2)
+    float *xsum;                      // h2x with vn.enable: [N][3] sum of the attention rows per atom (for a following VnFold), or nullptr
+    VnFold vf;                        // x2h: coordinate update of the previous layer in the prologue
 };
 
 // ONE = true: every wave has at most one job (jobs <= workgroups x waves; the common case up to ~6k atoms).
@@ -142,6 +162,8 @@ edge16_kernel(Edge16Args a) {
     int atom = 0, jn = 0, edge = 0;
     bool atom_ok = false, ok = false;
     float xi[3], xj[3];
+    bool fold = false;
+    if constexpr (!H2X) fold = a.vf.enable != 0;
     float4 ga[NT], gb[NT], gav[NT], gbv[NT];      // gathered rows: A_k[i], B_k[j], A_v[i], B_v[j]
     float4 qv[NT];                                // query row of the centre atom
     float wgt = 0.f;
@@ -159,15 +181,19 @@ edge16_kernel(Edge16Args a) {
         const float *pi = a.pre + (size_t)(SM_ABL(17) ? 0 : atom) * a.ld_pre;
 #pragma unroll
         for (int t = 0; t < NT; ++t) ga[t] = ldg4(pi + 16 * t + 4 * g);
+        if (!fold) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xi[k] = a.x[atom * 3 + k];
+            for (int k = 0; k < 3; ++k) xi[k] = a.x[atom * 3 + k];
+        }
         ok = atom_ok && jraw >= 0;
         jn = ok ? jraw : atom;
         const float *pj = a.pre + (size_t)(SM_ABL(17) ? 0 : jn) * a.ld_pre + H;
 #pragma unroll
         for (int t = 0; t < NT; ++t) gb[t] = ldg4(pj + 16 * t + 4 * g);
+        if (!fold) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xj[k] = a.x[jn * 3 + k];
+            for (int k = 0; k < 3; ++k) xj[k] = a.x[jn * 3 + k];
+        }
         wgt = a.ew[edge];
     };
     // the value MLP's rows and the query row are requested once the key rows have been consumed (register budget): they
@@ -210,6 +236,67 @@ edge16_kernel(Edge16Args a) {
     // row gathers (the long pole, ~3 us from the Infinity Cache) -> image DMA (1.7 us, lands meanwhile).
     // (SM_ABL(bit): timing-attribution builds only, build.sh --ablate MASK: 16 image DMA, 17 row gathers, 18 hidden layers,
     //  19 key second Linear + softmax, 20 value second Linear)
+    // ---- folded coordinate update of the previous layer (x2h): issued FIRST, its small loads are the oldest operations ----
+    float *xt = lds + V_BASE + IMV::TOTAL;                     // [kVnFoldCap][3] new coordinates of the touched molecules
+    int span0 = 0, span_n = 1;
+    if constexpr (!H2X) {
+        if (fold) {
+            double *sred = reinterpret_cast<double *>(xt + 3 * kVnFoldCap);          // [2][16] batch sums
+            const int first_atom = (a.job_base + blockIdx.x * nwave) * APJ;
+            const int last_atom = min(a.n_atoms, first_atom + nwave * APJ) - 1;
+            if (first_atom <= last_atom) {
+                span0 = a.vf.mol_off[a.vf.mol_of[first_atom]];
+                const int span = a.vf.mol_off[a.vf.mol_of[last_atom] + 1] - span0;
+                if (span > kVnFoldCap && threadIdx.x == 0) *a.vf.span_flag = 1;      // the max_mol_atoms hint was too small
+                span_n = min(span, kVnFoldCap);
+            }
+            if (threadIdx.x < 32) {
+                const int c = threadIdx.x & 15, which = threadIdx.x >> 4;
+                double t = 0.0;
+                if (c < HD) for (int r = 0; r < kVnReplicas; ++r) t += a.vf.acc[(size_t)r * 2 * HD + which * HD + c];
+                sred[threadIdx.x] = t;
+            }
+            __syncthreads();
+            const int c = lane & 15;
+            float meanf = 0.f, rstd = 0.f, bng = 0.f, bnb = 0.f;
+            if (c < HD) {
+                const double cnt = (double)a.n_atoms;
+                const double mean = sred[c] / cnt;
+                double var = sred[16 + c] / cnt - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                meanf = (float)mean;
+                rstd = 1.0f / sqrtf((float)var + 1e-5f);
+                bng = a.vf.bn_g[c]; bnb = a.vf.bn_b[c];
+            }
+            for (int it = threadIdx.x; it < span_n * 16; it += blockDim.x) {       // item = (atom of the span, channel)
+                const int va = span0 + (it >> 4);
+                float o[3] = {0.f, 0.f, 0.f};
+                if (c < HD) {
+                    const float *pdp = a.vf.pd + ((size_t)va * HD + c) * 6;
+                    float p[3] = {pdp[0], pdp[1], pdp[2]};
+                    const float d[3] = {pdp[3], pdp[4], pdp[5]};
+                    const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
+                    const float nbn = (nrm - meanf) * rstd * bng + bnb;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[k] = p[k] / nrm * nbn;
+                    const float dot = p[0] * d[0] + p[1] * d[1] + p[2] * d[2];
+                    const float dsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                    const float coef = dot / (dsq + 1e-6f);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) o[k] = 0.2f * p[k] + 0.8f * (dot >= 0.f ? p[k] : p[k] - coef * d[k]);
+                }
+                float res[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) res[k] = seg_sum<16>(o[k]);              // over the channels of the atom
+                if (c < 3) {
+                    const float r = c == 0 ? res[0] : (c == 1 ? res[1] : res[2]);
+                    const float xn = a.vf.x_old[va * 3 + c] + (a.vf.xsum[va * 3 + c] / HD + r / HD);
+                    xt[(it >> 4) * 3 + c] = xn;
+                    if (va >= first_atom && va <= last_atom) a.vf.x_new[va * 3 + c] = xn;
+                }
+            }
+        }
+    }
     if (have0) request(locate(job0));
     if (!SM_ABL(16)) {
         dma_to_lds(lds, a.image_k, IMK::TOTAL / 4, wave, nwave, lane);
@@ -231,6 +318,11 @@ edge16_kernel(Edge16Args a) {
         if constexpr (!ONE) asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
         if (!first) request(locate(job));
         first = false;
+        if (fold) {      // coordinates from the table the prologue built (the barrier above made it visible)
+            const int ia = min(max(atom - span0, 0), span_n - 1) * 3, ja = min(max(jn - span0, 0), span_n - 1) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { xi[k] = xt[ia + k]; xj[k] = xt[ja + k]; }
+        }
         const float rel[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
         u32x4 rh = {0u, 0u, 0u, 0u}, rl = {0u, 0u, 0u, 0u};
         {
@@ -379,6 +471,12 @@ edge16_kernel(Edge16Args a) {
                 }
                 float *out = a.vn.pd + ((size_t)va * HD + v_c) * 6;
                 out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
+                if (a.xsum && v_c < 3) {                     // sum over the attention rows (padding rows are zero), r ascending as vn_apply_kernel
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) { a0 += orow[rr * 3]; a1 += orow[rr * 3 + 1]; a2 += orow[rr * 3 + 2]; }
+                    a.xsum[va * 3 + v_c] = v_c == 0 ? a0 : (v_c == 1 ? a1 : a2);
+                }
                 const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
                 v_s1 += (double)nrm;
                 v_s2 += (double)nrm * (double)nrm;

@@ -9,7 +9,7 @@
 // (reference: batch_ligand = repeat_interleave(arange(B), counts), scripts/sample_diffusion.py:72)
 // ---------------------------------------------------------------------------------------------
 // status flags of a context (device int[8], sticky until the next _score/_sample; read by shapemol_status)
-enum StatusFlag { ST_VN_BARRIER = 0, ST_BATCH = 1, ST_ATOM_TYPE = 2, ST_TIME = 3, ST_RANGE = 4 };
+enum StatusFlag { ST_VN_BARRIER = 0, ST_BATCH = 1, ST_ATOM_TYPE = 2, ST_TIME = 3, ST_RANGE = 4, ST_SPAN = 5 };
 
 __global__ void mol_index_kernel(const int64_t *batch, int n, int n_mols, int *mol_of, int *mol_off, int *status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -232,6 +232,9 @@ class ScorePosNet3D(nn.Module):
                 raise ValueError("noise must be (eps (S,N,3), u (S,N,C))")
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
+        # the largest molecule of the batch lets the library fold the per-layer coordinate update into the next attention
+        # kernel (one tiny synchronising reduction per chain; the reference synchronises at every step)
+        _lib.check(lib.shapemol_set_option(ctx, b"max_mol_atoms", int(torch.bincount(batch).max().item()) if n else 0), "shapemol_set_option")
         guided = use_pointcloud_data is not None
         if guided:
             cloud = np.ascontiguousarray(np.asarray(use_pointcloud_data[0], dtype=np.float64).reshape(-1, 3))

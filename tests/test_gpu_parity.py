@@ -711,3 +711,33 @@ def test_fp16_range_guard_of_the_node_kernels():
         out = m(*args)
     m.check_status()
     assert torch.isfinite(out["pred_ligand_h"]).all()
+
+
+def test_folded_coordinate_update_equals_separate_launch():
+    """The coordinate update of a layer folded into the next x2h kernel (chains, default) against the separate vn_apply
+    launches: same chain to rounding; and a max_mol_atoms hint below the truth is reported, not silently wrong."""
+    from shapemol_amd import _lib
+    m = hip_model()
+    bb = synth.synthetic_batch(48, seed=9)
+    eps, u = hash_noise(len(bb["batch"]), 12, 9)
+    r1 = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], 12, eps, u)
+    c1 = int(m.debug_read("captures", (1,), np.int64)[0])
+    try:
+        m.set_option("vn_fold", 0)
+        r0 = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], 12, eps, u)
+    finally:
+        m.set_option("vn_fold", 1)
+    assert torch.equal(r1["v"], r0["v"]) and maxabs(r1["pos"], r0["pos"]) < 2e-5
+    assert maxabs(torch.stack(r1["pos_cond_traj"]), torch.stack(r0["pos_cond_traj"])) < 2e-5
+    # a hint that is too small: the kernel's span check raises the flag
+    from shapemol_amd.runtime import ChainRunner
+    big = synth.synthetic_batch(6, seed=2, atoms_range=(150, 160))
+    r = ChainRunner(m, len(big["batch"]), 6, 4, keep_traj=False)
+    r.load_batch(big["init_pos"], big["init_v"], big["batch"], big["shape"])
+    m.set_option("max_mol_atoms", 20)
+    r.run(3)
+    with pytest.raises(_lib.ShapeMolLibraryError, match="max_mol_atoms"):
+        r.synchronize()
+    r.load_batch(big["init_pos"], big["init_v"], big["batch"], big["shape"])      # restores the true hint: too large to fold -> plain path
+    r.run(3)
+    r.synchronize()
