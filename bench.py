@@ -146,8 +146,8 @@ def main():
         runner.synchronize()
         if dist is not None:
             gather_molecules(runner.out_pos, runner.out_v, counts)
-    barrier()
     log(f"timing {steps} steps")
+    barrier()
     t0 = time.perf_counter()
     runner.run(steps, seed=12, use_graph=use_graph)
     runner.synchronize()

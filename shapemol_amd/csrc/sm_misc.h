@@ -109,6 +109,22 @@ __global__ void shape_term_kernel(ShapeTermArgs a) {
     }
 }
 
+// all shape terms of a chain in one launch: grid (B, n_terms), the argument blocks in device memory
+__global__ void shape_term_multi_kernel(const ShapeTermArgs *terms) {
+    const ShapeTermArgs a = terms[blockIdx.y];
+    const int b = blockIdx.x;
+    for (int f = threadIdx.x; f < 4 * a.H; f += blockDim.x) {
+        const int blk = f / a.H, ff = f % a.H;
+        float v = 0.f;
+        if ((blk & 1) == 0) {
+            const float *w = (blk == 0 ? a.wk : a.wv) + (size_t)ff * a.ldw;
+            v = (blk == 0 ? a.bk : a.bv)[ff];
+            for (int i = 0; i < a.SL; ++i) v += w[i] * a.inv[(size_t)b * a.SL + i];
+        }
+        a.add[(size_t)b * a.ld + f] = v;
+    }
+}
+
 // Shape part of the VN-linear inputs (step-invariant): ps[b][which][c][dim] =
 //   sum_s W_which[c][1 + heads + s] * shape[b][s][dim]      (tmp_output concat, uni_transformer.py:154)
 struct VnShapeArgs {
@@ -124,6 +140,19 @@ __global__ void vn_shape_kernel(VnShapeArgs a) {
         const float *w = (which ? a.wd : a.wf) + (size_t)c * cin + 1 + a.heads;
         float v = 0.f;
         for (int s = 0; s < a.S; ++s) v += w[s] * a.shape[((size_t)b * a.S + s) * 3 + dim];
+        a.ps[(size_t)b * 2 * per + idx] = v;
+    }
+}
+
+// all layers in one launch: grid (B, L); `shape` is the call's argument, the rest comes from the device-side blocks
+__global__ void vn_shape_multi_kernel(const float *shape, const VnShapeArgs *layers) {
+    VnShapeArgs a = layers[blockIdx.y];
+    const int b = blockIdx.x, per = a.heads * 3, cin = 1 + a.heads + a.S;
+    for (int idx = threadIdx.x; idx < 2 * per; idx += blockDim.x) {
+        const int which = idx / per, c = (idx % per) / 3, dim = idx % 3;
+        const float *w = (which ? a.wd : a.wf) + (size_t)c * cin + 1 + a.heads;
+        float v = 0.f;
+        for (int s = 0; s < a.S; ++s) v += w[s] * shape[((size_t)b * a.S + s) * 3 + dim];
         a.ps[(size_t)b * 2 * per + idx] = v;
     }
 }
