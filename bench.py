@@ -208,7 +208,9 @@ def main():
                       "edge_h2x": ((dm.G * dm.H + HH) + (dm.G * dm.H + dm.H * dm.heads)) * 2 * dm.k * n_atoms,
                       "node_chain": 14 * HH * n_atoms,          # out MLP (2H->H->H) + two follow-up MLPs (H->H->H)
                       "node_pre": 16 * HH * n_atoms}            # 8H x H paired products (the first launch does 4H)
-        flops = per_launch.get(dom, 0.0)
+        # larger batches run a class's work of a layer as several launches (slices): FLOPs per ACTUAL launch
+        slices = max(1.0, dom_n / (8.0 * max(1, args.profile_steps)))
+        flops = per_launch.get(dom, 0.0) / slices
         ach = flops / avg_s / 1e12 if flops else 0.0
         # HBM bytes per launch of that kernel from the committed PMC passes of the same workload (rocprofv3 cannot run
         # inside this process); null when no committed pass matches the batch size
@@ -224,6 +226,8 @@ def main():
         pieces = {"edge_x2h": 3 * 2 * (2 * HH + 2 * 32 * dm.H) * dm.k * n_atoms,
                   "edge_h2x": 3 * 2 * ((HH + 32 * dm.H) + (16 * dm.H + 32 * dm.H)) * dm.k * n_atoms,
                   "node_chain": 3 * 14 * HH * n_atoms, "node_pre": 3 * 16 * HH * n_atoms}.get(dom)
+        if pieces:
+            pieces /= slices
         step_exec = f_exec_total * n_atoms / sec_per_step / 1e12
         # ceiling of the formulation the kernel runs: every fp32 product is three f16 (edge, node) piece products on the
         # f16 matrix cores, so the algorithm's fp32 FLOPs are bounded by the dense f16 peak / 3
