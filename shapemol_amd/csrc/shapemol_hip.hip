@@ -452,6 +452,7 @@ struct shapemol_ctx {
     float *temb = nullptr, *inv = nullptr, *add0 = nullptr, *addp = nullptr, *ps = nullptr, *ew = nullptr;
     float *h_a = nullptr, *h_b = nullptr, *pre0 = nullptr, *preAB = nullptr, *q_x = nullptr, *q_h = nullptr, *att = nullptr, *o3 = nullptr, *pd = nullptr;
     ShapeTermArgs *prep_terms = nullptr; VnShapeArgs *prep_vn = nullptr; int n_prep_terms = 0;   // argument blocks of run_prep's two batched launches
+    int2 *mol_span = nullptr;   // [N] molecule span of every atom
     float *xsum = nullptr;      // [N][3] per-atom sum of the h2x attention rows (folded coordinate update)
     float *alpha = nullptr;     // [N*KP][2][NT] attention weights handed from the key phase to the value phase
     float *x_a = nullptr, *x_b = nullptr, *x_state = nullptr, *pred_pos = nullptr, *pred_v = nullptr;
@@ -548,7 +549,7 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
         A(&c->steps, 4) || A(&c->temb, capB * g.time_emb_dim) || A(&c->inv, capB * g.shape_latent_dim) ||
         A(&c->add0, (size_t)capB * 4 * H) || A(&c->addp, (size_t)L * capB * 8 * H) || A(&c->ps, (size_t)L * capB * 2 * hd * 3) || A(&c->ew, capN * c->KP) ||
         A(&c->h_a, capN * H) || A(&c->h_b, capN * H) || A(&c->pre0, capN * 4 * H) || A(&c->preAB, capN * 8 * H) || A(&c->q_x, capN * H) || A(&c->q_h, capN * H) ||
-        A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->xsum, capN * 3) || A(&c->alpha, capN * c->KP * 2 * (H / 16)) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
+        A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->xsum, capN * 3) || A(&c->mol_span, capN) || A(&c->alpha, capN * c->KP * 2 * (H / 16)) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
         A(&c->x_b, capN * 3) || A(&c->x_state, capN * 3) || A(&c->pred_pos, capN * 3) ||
         A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * kBnReplicas * 2 * hd + L + 1) ||
         A(&c->status, 8) || A(&c->chain_params, 1) || A(&c->prep_terms, 2 * L + 1) || A(&c->prep_vn, L))
@@ -755,6 +756,7 @@ int run_prep(shapemol_ctx *c, hipStream_t s, const int64_t *d_batch, int64_t N, 
     const shapemol_config &g = c->cfg;
     const int L = g.num_layers, hd = g.n_heads, SL = g.shape_latent_dim, S = g.shape_dim;
     LAUNCH("prep", SMK(mol_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_batch, (int)N, (int)B, c->mol_of, c->mol_off, c->status));
+    LAUNCH("prep", SMK(mol_span_kernel, dim3((N + 255) / 256), dim3(256), 0, s, c->mol_of, c->mol_off, (int)N, c->mol_span));
     ShapeInvArgs si{d_shape, c->P(c->dm.inv.w1), c->P(c->dm.inv.b1), c->P(c->dm.inv.g), c->P(c->dm.inv.be),
                     c->P(c->dm.inv.w2), c->P(c->dm.inv.b2), c->inv, S, SL};
     LAUNCH("prep", SMK(shape_invariant_kernel, dim3(B), dim3(64), 0, s, si));
@@ -875,7 +877,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                 if (fold && has_next) {      // no vn_apply launch: the next x2h kernel finishes the update
                     ea.xsum = c->xsum;
                     pending = VnFold{c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, x_next,
-                                     c->mol_of, c->mol_off, c->status + ST_SPAN, 1};
+                                     c->mol_span, c->status + ST_SPAN, 1};
                     vn_done = true;
                 }
             }

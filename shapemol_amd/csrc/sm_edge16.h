@@ -115,7 +115,7 @@ struct VnFold {
     const float *xsum;        // [N][3] sum over the attention rows, written by the h2x epilogue
     const float *x_old;       // [N][3]
     float *x_new;             // [N][3]
-    const int *mol_of, *mol_off;
+    const int2 *mol_span;     // [N] first / one-past-last atom of each atom's molecule
     int *span_flag;           // status flag raised if a workgroup's molecule span exceeds the table
     int enable;
 };
@@ -245,8 +245,8 @@ edge16_kernel(Edge16Args a) {
             const int first_atom = (a.job_base + blockIdx.x * nwave) * APJ;
             const int last_atom = min(a.n_atoms, first_atom + nwave * APJ) - 1;
             if (first_atom <= last_atom) {
-                span0 = a.vf.mol_off[a.vf.mol_of[first_atom]];
-                const int span = a.vf.mol_off[a.vf.mol_of[last_atom] + 1] - span0;
+                span0 = a.vf.mol_span[first_atom].x;
+                const int span = a.vf.mol_span[last_atom].y - span0;
                 if (span > kVnFoldCap && threadIdx.x == 0) *a.vf.span_flag = 1;      // the max_mol_atoms hint was too small
                 span_n = min(span, kVnFoldCap);
             }

@@ -25,6 +25,13 @@ __global__ void mol_index_kernel(const int64_t *batch, int n, int n_mols, int *m
         for (int m = b + 1; m <= n_mols; ++m) mol_off[m] = n;
 }
 
+// first / one-past-last atom of every atom's molecule (step-invariant; read by the folded coordinate update of the x2h
+// kernel, which would otherwise chase mol_of -> mol_off before it can request anything)
+__global__ void mol_span_kernel(const int *mol_of, const int *mol_off, int n, int2 *span) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) span[i] = int2{mol_off[mol_of[i]], mol_off[mol_of[i] + 1]};
+}
+
 __global__ void t_convert_kernel(const int64_t *t, int n_mols, int n_timesteps, int *t_mol, int *status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_mols) return;

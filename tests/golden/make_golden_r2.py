@@ -157,21 +157,31 @@ def shape_encoder_fixture():
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+    # float32 reductions of the CPU BLAS depend on the thread count: every fixture records the count it was made with
+    # (the 47-minute B=256 chain ran on 6 threads beside a build, the k=32 set on 3), and a regeneration uses the same
+    threads = {"b256": 6, "b1024": 8, "k32": 3, "guide": 8, "se": 8}
+    def use_threads(task):
+        torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", threads[task])))
+    torch.set_num_threads(8)
     if what in ("b256", "b1024", "all"):
         model, _ = G.load_reference_model()
         G.synthetic_load(model, seed=7)
         if what in ("b1024", "all"):
+            use_threads("b1024")
             chain(model, "b1024_s50", 1024, 50, 14, every=10, head=2, max_atoms=38)
         if what in ("b256", "all"):
+            use_threads("b256")
             chain(model, "b256_s1000", 256, 1000, 13, every=50, head=4, max_atoms=38)
     if what in ("se", "all"):
+        use_threads("se")
         G.install_stand_ins()
         shape_encoder_fixture()
     if what in ("guide", "all"):
+        use_threads("guide")
         G.install_stand_ins()
         guidance_fixtures()
     if what in ("k32", "all"):
+        use_threads("k32")
         # configs[4] analogue: 40-80 atom molecules, knn = 32, full depth
         m2, _ = G.load_reference_model(dict(knn=32))
         G.synthetic_load(m2, seed=9)
