@@ -1095,7 +1095,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
                        run_score<32>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v))) return 1;
         if (c->g_points > 0) {     // point-cloud shape guidance of the predicted x0 (steps with t > grad_step)
             PcGuideArgs ga{c->pred_pos, c->g_cloud, c->chain_params, c->steps + 1, (int)N, (int)c->g_points, t_first, c->g_grad_step, c->g_radius};
-            LAUNCH("pc_guidance", SMK(pc_guidance_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, s, ga));
+            LAUNCH("pc_guidance", SMK(pc_guidance_kernel, dim3((N * 16 + 255) / 256), dim3(256), (size_t)c->g_points * 24, s, ga));
         }
         return DISPATCH_H(c, run_ddpm<128>(c, s, N), run_ddpm<32>(c, s, N));
     };
@@ -1214,7 +1214,7 @@ int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t
 
 int shapemol_set_guidance(shapemol_ctx *c, const double *h_cloud, int64_t n_points, double radius, int32_t grad_step, const double *d_draws) {
     if (!c) return fail("shapemol_set_guidance: null ctx");
-    if (n_points < 0 || n_points > (1 << 22) || (n_points > 0 && n_points < 3)) return fail("shapemol_set_guidance: the cloud needs at least 3 points");
+    if (n_points < 0 || n_points > 2048 || (n_points > 0 && n_points < 3)) return fail("shapemol_set_guidance: the cloud needs 3 .. 2048 points (it is staged in LDS)");
     if (n_points > 0 && (!h_cloud || !(radius > 0.0))) return fail("shapemol_set_guidance: cloud / radius missing");
     HIPCHK(hipSetDevice(c->device));
     c->drop_graphs();                            // also drains the device: the old cloud may still be in use
@@ -1237,7 +1237,7 @@ int shapemol_guide_points(shapemol_ctx *c, float *d_pos, int64_t N, const double
     cp.seed = seed; cp.guide_draws = d_draws; cp.step_base = 0;
     LAUNCH("prep", SMK(set_chain_params_kernel, dim3(1), dim3(1), 0, s, c->chain_params, cp, c->steps));
     PcGuideArgs ga{d_pos, c->g_cloud, c->chain_params, nullptr, (int)N, (int)c->g_points, c->g_grad_step + 1, c->g_grad_step, c->g_radius};
-    LAUNCH("pc_guidance", SMK(pc_guidance_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, s, ga));
+    LAUNCH("pc_guidance", SMK(pc_guidance_kernel, dim3((N * 16 + 255) / 256), dim3(256), (size_t)c->g_points * 24, s, ga));
     return 0;
 }
 

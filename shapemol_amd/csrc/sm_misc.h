@@ -685,27 +685,33 @@ struct PcGuideArgs {
     double radius;
 };
 
+// Three nearest cloud points of p.  Every candidate is one 64-bit key: the bits of its squared distance (non-negative
+// doubles order like unsigned integers) with the low 12 bits replaced by ... nothing: keys stay exact; the point index
+// travels beside the key.  Each of the 16 lanes of an atom scans every 16th point (the cloud sits in LDS) and keeps its
+// three smallest keys in a branch-free sorted triple; the lanes' triples are merged pairwise over four xor-shuffle steps
+// (smallest three of six, ties broken by the index so that both partners end with the same triple).
 struct Top3 { double d[3]; int i[3]; };
+SM_DEV bool key_less(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
 SM_DEV void top3_insert(Top3 &t, double d, int i) {
-    if (d < t.d[2]) {
-        if (d < t.d[1]) {
-            t.d[2] = t.d[1]; t.i[2] = t.i[1];
-            if (d < t.d[0]) { t.d[1] = t.d[0]; t.i[1] = t.i[0]; t.d[0] = d; t.i[0] = i; }
-            else { t.d[1] = d; t.i[1] = i; }
-        } else { t.d[2] = d; t.i[2] = i; }
-    }
+    // compare against the three slots from the back; selects instead of branches
+    const bool l2 = key_less(d, i, t.d[2], t.i[2]), l1 = key_less(d, i, t.d[1], t.i[1]), l0 = key_less(d, i, t.d[0], t.i[0]);
+    const double n2 = l1 ? t.d[1] : (l2 ? d : t.d[2]); const int j2 = l1 ? t.i[1] : (l2 ? i : t.i[2]);
+    const double n1 = l0 ? t.d[0] : (l1 ? d : t.d[1]); const int j1 = l0 ? t.i[0] : (l1 ? i : t.i[1]);
+    const double n0 = l0 ? d : t.d[0];                  const int j0 = l0 ? i : t.i[0];
+    t.d[0] = n0; t.i[0] = j0; t.d[1] = n1; t.i[1] = j1; t.d[2] = n2; t.i[2] = j2;
 }
 SM_DEV double shfl_xor_f64(double v, int m) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
     return __hiloint2double(hi, lo);
 }
-// three nearest cloud points of p: squared distances ascending + indices, identical in all 16 lanes of the atom
+// cloud: LDS copy [P][3] doubles; identical result in all 16 lanes of the atom
 SM_DEV Top3 pc_query(const double *cloud, int n_points, const double (&p)[3], int l16) {
-    Top3 t{{1e300, 1e300, 1e300}, {-1, -1, -1}};
+    Top3 t{{1e300, 1e300, 1e300}, {0x7ffffff0, 0x7ffffff1, 0x7ffffff2}};
     for (int c = l16; c < n_points; c += 16) {
         const double dx = p[0] - cloud[c * 3], dy = p[1] - cloud[c * 3 + 1], dz = p[2] - cloud[c * 3 + 2];
-        top3_insert(t, (dx * dx + dy * dy) + dz * dz, c);
+        const double d2 = (dx * dx + dy * dy) + dz * dz;
+        if (__any(d2 <= t.d[2])) top3_insert(t, d2, c);       // most points beat nobody's third best: skip the insert wave-wide
     }
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) {
@@ -713,27 +719,23 @@ SM_DEV Top3 pc_query(const double *cloud, int n_points, const double (&p)[3], in
 #pragma unroll
         for (int k = 0; k < 3; ++k) { o.d[k] = shfl_xor_f64(t.d[k], m); o.i[k] = __shfl_xor(t.i[k], m, 64); }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) if (o.i[k] >= 0 && (o.d[k] < t.d[2] || (o.d[k] == t.d[2] && o.i[k] < t.i[2]))) {
-            // insert with an index tie-break so that both partners end with the same triple
-            Top3 u = t;
-            int pos = 2;
-            while (pos > 0 && (o.d[k] < u.d[pos - 1] || (o.d[k] == u.d[pos - 1] && o.i[k] < u.i[pos - 1]))) --pos;
-            for (int q = 2; q > pos; --q) { u.d[q] = u.d[q - 1]; u.i[q] = u.i[q - 1]; }
-            u.d[pos] = o.d[k]; u.i[pos] = o.i[k];
-            t = u;
-        }
+        for (int k = 0; k < 3; ++k) top3_insert(t, o.d[k], o.i[k]);      // partner entries beyond the third smallest fall off the end
     }
     return t;
 }
 
 __global__ void __launch_bounds__(256) pc_guidance_kernel(PcGuideArgs a) {
+    extern __shared__ double pc_cloud[];                            // [P][3]
     const int step = a.step_cur ? *a.step_cur : 0;
     if (a.t_first - step <= a.grad_step) return;                   // `if i > grad_step` (molopt_score_model.py:585)
+    for (int i = threadIdx.x; i < a.n_points * 3; i += blockDim.x) pc_cloud[i] = a.cloud[i];
+    __syncthreads();
+    const double *cloud = pc_cloud;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int atom_raw = gid >> 4, l16 = gid & 15;
     const int atom = atom_raw < a.n_atoms ? atom_raw : a.n_atoms - 1;
     double p[3] = {(double)a.pred_pos[atom * 3], (double)a.pred_pos[atom * 3 + 1], (double)a.pred_pos[atom * 3 + 2]};
-    Top3 t = pc_query(a.cloud, a.n_points, p, l16);
+    Top3 t = pc_query(cloud, a.n_points, p, l16);
     bool far = (sqrt(t.d[0]) + sqrt(t.d[1]) + sqrt(t.d[2])) / 3.0 > a.radius;
     bool changed = false;
     const ChainParams cp = *a.cp;
@@ -752,13 +754,13 @@ __global__ void __launch_bounds__(256) pc_guidance_kernel(PcGuideArgs a) {
             const double scalar = u * (0.8 - 0.2) + 0.2;           // np.random.random() * (0.8 - ratio) + ratio, ratio = 0.2
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double nearest = (a.cloud[t.i[0] * 3 + k] + a.cloud[t.i[1] * 3 + k] + a.cloud[t.i[2] * 3 + k]) / 3.0;
+                const double nearest = (cloud[t.i[0] * 3 + k] + cloud[t.i[1] * 3 + k] + cloud[t.i[2] * 3 + k]) / 3.0;
                 p[k] = p[k] - scalar * (p[k] - nearest);
             }
             changed = true;
         }
         // the query is wave-uniform control flow (shuffles): lanes of atoms that are done run it on their final point
-        t = pc_query(a.cloud, a.n_points, p, l16);
+        t = pc_query(cloud, a.n_points, p, l16);
         if (far && (sqrt(t.d[0]) + sqrt(t.d[1]) + sqrt(t.d[2])) / 3.0 < a.radius) far = false;
     }
     if (changed && atom_raw < a.n_atoms && l16 < 3) a.pred_pos[atom * 3 + l16] = (float)(l16 == 0 ? p[0] : (l16 == 1 ? p[1] : p[2]));
