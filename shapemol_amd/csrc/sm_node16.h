@@ -187,6 +187,7 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
     auto atom_of = [&](int c) { return min((ct0 + c) * 16 + n, a.n_atoms - 1); };
     auto atom_ok = [&](int c) { return (ct0 + c) * 16 + n < a.n_atoms; };
 
+    SM_TICK(a.stamps, 0);
     // ---- stage 0: weights of the output MLP; [att | h] tiles -> fragments ----------------------------
     u32x4 w1[2][2 * NB], w2[2][NB];
     N16::template load_w<2 * NB>(a.w1img6, ot, lane, w1);
@@ -207,6 +208,7 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
     for (int c = 0; c < CC; ++c) hres[c] = ldg4(a.h + (size_t)atom_of(c) * H + f0);    // residual
     const float4 b1 = ldg4(a.b1 + f0), b2 = ldg4(a.b2 + f0);
     __syncthreads();
+    SM_TICK(a.stamps, 1);
 
     // ---- stage 1: h' = h + W2 relu(LN(W1 [att | h] + b1)) + b2 ---------------------------------------
     {
@@ -220,8 +222,10 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
     if (a.n_follow > 0) N16::template load_w<NB>(a.f[0].w1img6, ot, lane, wf0);
     if (a.n_follow > 1) N16::template load_w<NB>(a.f[1].w1img6, ot, lane, wf1);
     __syncthreads();
+    SM_TICK(a.stamps, 2);
     N16::normalise(pre0, NODE_LN_RELU, a.ln_g, a.ln_b, fhid0, ot, lane, range_flag);
     __syncthreads();
+    SM_TICK(a.stamps, 3);
     {
         f32x4 acc[CC];
 #pragma unroll
@@ -246,6 +250,7 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
     u32x4 wg0[2][NB], wg1[2][NB];                                    // second Linears of the follow-up MLPs
     if (on0) N16::template load_w<NB>(a.f[0].w2img6, ot, lane, wg0);
     __syncthreads();
+    SM_TICK(a.stamps, 4);
 
     // ---- stage 2: follow-up MLPs on the new h ---------------------------------------------------------
     {
@@ -293,9 +298,11 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
         }
     }
     __syncthreads();
+    SM_TICK(a.stamps, 5);
     N16::normalise(pre0, a.f[0].mode, a.f[0].ln_g, a.f[0].ln_b, fhid0, ot, lane, range_flag);
     if (a.n_follow > 1) N16::normalise(pre1, a.f[1].mode, a.f[1].ln_g, a.f[1].ln_b, fhid1, ot, lane, range_flag);
     __syncthreads();
+    SM_TICK(a.stamps, 6);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (!(k == 0 ? on0 : on1)) continue;
@@ -318,6 +325,7 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
             }
         }
     }
+    SM_STAMP(a.stamps, 7);
 }
 
 template <int H>

@@ -5,7 +5,7 @@ Same harness as make_golden.py (the reference's own ``models`` package is import
 container and filled with the hash weights of ``shapemol_amd.synth``); kept in a second script
 because these take tens of CPU-minutes while make_golden.py's set regenerates in a few.
 
-    python tests/golden/make_golden_r2.py b256      # configs[1]: B=256 x 1000 steps   (~30 min)
+    python tests/golden/make_golden_r2.py b256      # configs[1]: B=256 x 1000 steps   (20-47 min)
     python tests/golden/make_golden_r2.py b1024     # configs[2]: B=1024 x 50 steps    (~6 min)
     python tests/golden/make_golden_r2.py k32       # configs[4]: <=80 atoms, k=32, L=8, B=64
     python tests/golden/make_golden_r2.py guide     # point-cloud shape guidance: the function alone and inside a chain
