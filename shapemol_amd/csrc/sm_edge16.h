@@ -33,12 +33,16 @@ SM_DEV f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
 }
 
 // two floats -> {hi pair, lo pair}, each one u32 of two f16 (low half = x0)
+// lo = f16(x - hi) by v_fma_mix{lo,hi}_f16: the product-sum hi * (-1) + x is formed in fp32 (exact: hi is x rounded to 11
+// bits) from the f16 half of `hi` directly and rounded to nearest into one half of `lo` -- three instructions per pair
+// where convert-back, subtract, convert take six; the same values bit for bit.
 SM_DEV void split2_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
     const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
-    const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
-    const f16x2 l = __builtin_convertvector(f32x2{r0, r1}, f16x2);
     hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+    lo = l;
 }
 
 // D-layout activations -> B fragments of the NT / 2 k-steps (two pieces each)
