@@ -208,6 +208,7 @@ def main():
                       "edge_h2x": ((dm.G * dm.H + HH) + (dm.G * dm.H + dm.H * dm.heads)) * 2 * dm.k * n_atoms,
                       "node_chain": 14 * HH * n_atoms,          # out MLP (2H->H->H) + two follow-up MLPs (H->H->H)
                       "node_pre": 16 * HH * n_atoms}            # 8H x H paired products (the first launch does 4H)
+        per_launch["edge_x2h_chain"] = per_launch["edge_x2h"] + per_launch["node_chain"]      # x2h_chain16_kernel: both in one launch
         # larger batches run a class's work of a layer as several launches (slices): FLOPs per ACTUAL launch
         slices = max(1.0, dom_n / (8.0 * max(1, args.profile_steps)))
         flops = per_launch.get(dom, 0.0) / slices
@@ -225,7 +226,9 @@ def main():
         # matrix instructions the dominant kernel really issues (f16 or bf16 piece products), against the 2.5 PFLOP/s peak
         pieces = {"edge_x2h": 3 * 2 * (2 * HH + 2 * 32 * dm.H) * dm.k * n_atoms,
                   "edge_h2x": 3 * 2 * ((HH + 32 * dm.H) + (16 * dm.H + 32 * dm.H)) * dm.k * n_atoms,
-                  "node_chain": 3 * 14 * HH * n_atoms, "node_pre": 3 * 16 * HH * n_atoms}.get(dom)
+                  "node_chain": 3 * 14 * HH * n_atoms, "node_pre": 3 * 16 * HH * n_atoms}
+        pieces["edge_x2h_chain"] = pieces["edge_x2h"] + pieces["node_chain"]
+        pieces = pieces.get(dom)
         if pieces:
             pieces /= slices
         step_exec = f_exec_total * n_atoms / sec_per_step / 1e12

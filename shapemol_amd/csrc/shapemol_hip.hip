@@ -472,6 +472,7 @@ struct shapemol_ctx {
     int vn_fold = 1;            // coordinate update of layer l in the prologue of the x2h kernel of layer l + 1 (needs max_mol_atoms)
     int max_mol_atoms = 0;      // largest molecule of the batches to come (option; 0 = unknown: no fold)
     int lin_fuse = 0;           // 1: per-node products of the next attentions inside node_chain16_kernel instead of a node_linear
+    int x2h_chain = 1;          // 1: x2h attention and the node stage of a layer in one launch (x2h_chain16_kernel) when every wave has one job
                                 // launch (measured: 28.5 us against 15.3 + 11.1 us, eight dependent weight blocks per wave)
     int node_f16 = 1;           // node kernels on two-piece f16 operands (sm_node16.h) instead of exactly split bf16 (sm_node.h)
     int edge_tiles = 0;         // f16 edge kernels when the waves have several jobs: 0 = sliced launches of the one-job kernel [default],
@@ -613,7 +614,8 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)x2h_chain16_kernel<H, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes));
 #define SETATTR5(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge16x2_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16x2_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + 512 * 16));
@@ -705,6 +707,30 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
     if (KP == 8) LAUNCH(nm, SMK((edge16x2_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     else if (KP == 16) LAUNCH(nm, SMK((edge16x2_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     else LAUNCH(nm, SMK((edge16x2_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    return 0;
+}
+
+// x2h attention + node stage in one launch: possible when the f16 kernels are in use, every wave gets one job in a single
+// launch, and a workgroup has at least H / 16 waves (the node stage's output blocks)
+template <int H>
+bool x2h_chain_ok(const shapemol_ctx *c, int n_atoms) {
+    if (!c->x2h_chain || c->edge_bf16 != 3 || c->KP > 16 || !c->chain_bf16 || !c->node_f16 || c->lin_fuse || c->edge_threads > 0) return false;
+    const int apj = 16 / c->KP, njobs = (n_atoms + apj - 1) / apj;
+    const int waves = std::max(H / 16, edge_waves_for(c, njobs));
+    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
+    return waves <= 12 && waves * apj <= CHAIN_COLS * 16 && njobs <= grid * waves && Chain16Lds<H>::BYTES <= 2 * EdgeImage16<H, H / 16>::TOTAL * 4;
+}
+
+template <int H>
+int launch_x2h_chain(shapemol_ctx *c, hipStream_t s, const Edge16Args &a, const NodeChainArgs &na) {
+    const int KP = c->KP, apj = 16 / KP;
+    const int njobs = (a.n_atoms + apj - 1) / apj, waves = std::max(H / 16, edge_waves_for(c, njobs));
+    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
+    const size_t shm = 2 * EdgeImage16<H, H / 16>::TOTAL * sizeof(float) + (a.vf.enable ? kVnFoldBytes : 0);
+    Edge16Args b = a;
+    b.job_base = 0; b.job_end = njobs;
+    if (KP == 8) LAUNCH("edge_x2h_chain", SMK((x2h_chain16_kernel<H, 8>), dim3(grid), dim3(waves * 64), shm, s, b, na, c->status + ST_RANGE));
+    else LAUNCH("edge_x2h_chain", SMK((x2h_chain16_kernel<H, 16>), dim3(grid), dim3(waves * 64), shm, s, b, na, c->status + ST_RANGE));
     return 0;
 }
 
@@ -819,13 +845,15 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         const bool last = (l == nlay - 1), has_next = !last;
         const bool phases = c->edge_bf16 && KP <= 16;
         const bool f16 = c->edge_bf16 == 3;     // two-piece f16 operands (sm_edge16.h), the default
+        const bool xc_fused = f16 && x2h_chain_ok<H>(c, n);
+        Edge16Args xea{};
         if (f16) {   // x2h attention: both MLP images resident, one barrier
-            Edge16Args ea{};
+            Edge16Args &ea = xea;
             ea.image_k = c->P(Dl.i16_kx); ea.image_v = c->P(Dl.i16_vx);
             ea.pre = l == 0 ? c->pre0 : c->preAB + 4 * H; ea.q = c->q_x; ea.x = cur_x; ea.nbr = c->nbr; ea.ew = c->ew; ea.out = c->att;
             ea.n_atoms = n; ea.ld_pre = l == 0 ? 4 * H : 8 * H; ea.stamps = (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr;
             ea.vf = pending; pending = VnFold{};
-            if (launch_edge16<H, false>(c, s, ea)) return 1;
+            if (!xc_fused && launch_edge16<H, false>(c, s, ea)) return 1;     // (fused: launched with the node stage below)
         } else if (phases && c->edge_bf16 == 1) {   // x2h attention, key and value phase in one launch
             EdgeFusedArgs fa{c->P(Dl.img_kx), c->P(Dl.img_vx), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew,
                              c->alpha, c->att, n, l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
@@ -854,7 +882,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                 na.lin_img16 = c->P(Dl.lin16_img); na.add_mol = c->addp + (size_t)l * c->capB * 8 * H; na.mol_of = c->mol_of;
                 na.pre_out = c->preAB; na.n_lin_tiles = lin_tiles; na.ld_add = 8 * H; na.ld_out = 8 * H;
             }
-            if (c->chain_bf16 && c->node_f16) LAUNCH("node_chain", SMK(node_chain16_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain16Lds<H>::BYTES, s, na, c->status + ST_RANGE));
+            if (xc_fused) { if (launch_x2h_chain<H>(c, s, xea, na)) return 1; }
+            else if (c->chain_bf16 && c->node_f16) LAUNCH("node_chain", SMK(node_chain16_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain16Lds<H>::BYTES, s, na, c->status + ST_RANGE));
             else if (c->chain_bf16) LAUNCH("node_chain", SMK(node_chain6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain6Lds<H>::BYTES, s, na));
             else LAUNCH("node_chain", SMK(node_chain_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), 0, s, na));
             cur_h = dst;
@@ -1170,6 +1199,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     else if (k == "edge_tiles") { if (value < 0 || value > 2) return fail("edge_tiles must be 0, 1 or 2"); c->edge_tiles = (int)value; }
     else if (k == "node_f16") c->node_f16 = value != 0;
     else if (k == "lin_fuse") c->lin_fuse = value != 0;
+    else if (k == "x2h_chain") c->x2h_chain = value != 0;
     else if (k == "vn_fold") c->vn_fold = value != 0;
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "chain_bf16") c->chain_bf16 = (int)value;

@@ -141,10 +141,13 @@ struct Edge16Args {
 };
 
 // ONE = true: every wave has at most one job (jobs <= workgroups x waves; the common case up to ~6k atoms).
-template <int H, int KP, bool H2X, bool ONE = false>
-__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
-edge16_kernel(Edge16Args a) {
+// KEEP (x2h, ONE): the attention rows are not stored; the storing lanes (n % SEGW == 0: lane (n, g) owns features
+// 16 t + 4 g .. + 3 of centre atom n / SEGW of the wave's job) return them in keep[t] for a node stage fused behind
+// (x2h_chain16_kernel, sm_node16.h); all other lanes return zeros.
+template <int H, int KP, bool H2X, bool ONE, bool KEEP>
+SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
     static_assert(KP == 8 || KP == 16, "single-tile jobs");
+    static_assert(!KEEP || (ONE && !H2X), "KEEP: one-job x2h only");
     constexpr int NT = H / 16;
     constexpr int NT2V = H2X ? 1 : NT;
     using IMK = EdgeImage16<H, NT>;
@@ -233,6 +236,10 @@ edge16_kernel(Edge16Args a) {
     };
 
     const bool have0 = job0 < njobs;
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) keep[t] = float4{0.f, 0.f, 0.f, 0.f};
+    }
     SM_TICK(a.stamps, 0);
     // both weight images by LDS-DMA (asynchronous, no register staging); the job's row gathers fly beside them
     // Order of the wave's memory operations (they complete in order, and the compiler cannot count the DMA pieces of a
@@ -401,7 +408,9 @@ edge16_kernel(Edge16Args a) {
                     float o[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = seg_sum<SEGW>(aw * v[r]);
-                    if (store) stg4(op + 16 * t + 4 * g, float4{o[0] + sw * bb.x, o[1] + sw * bb.y, o[2] + sw * bb.z, o[3] + sw * bb.w});
+                    const float4 row = {o[0] + sw * bb.x, o[1] + sw * bb.y, o[2] + sw * bb.z, o[3] + sw * bb.w};
+                    if constexpr (KEEP) keep[t] = store ? row : float4{0.f, 0.f, 0.f, 0.f};
+                    else if (store) stg4(op + 16 * t + 4 * g, row);
                 }
             } else {
                 const float4 bb = ldg4(b2 + 4 * g);
@@ -500,6 +509,13 @@ edge16_kernel(Edge16Args a) {
             atomicAdd(acc + HD + threadIdx.x, s2);
         }
     }
+}
+
+template <int H, int KP, bool H2X, bool ONE = false>
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
+edge16_kernel(Edge16Args a) {
+    float4 keep[H / 16];
+    edge16_body<H, KP, H2X, ONE, false>(a, keep);
 }
 
 // -------------------------------------------------------------------------------------------------------------------

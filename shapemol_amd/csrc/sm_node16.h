@@ -168,9 +168,16 @@ struct Node16 {
     }
 };
 
-template <int H>
-__global__ void __launch_bounds__(H * 4)
-node_chain16_kernel(NodeChainArgs a, int *range_flag) {
+// The node stage of a layer on the column block [first_atom, first_atom + ncols) (ncols <= 16 CC), waves 0 .. NT - 1 owning
+// one 16-row block of output features each.
+//   FUSED = false: the body of node_chain16_kernel (a workgroup of NT waves; [att | h] rows staged from global memory).
+//   FUSED = true:  the tail of x2h_chain16_kernel: the workgroup's waves (>= NT of them) have just produced the attention rows
+//                  of these atoms (keep[], storing lanes only: edge16_body<KEEP>); the LDS they read the edge images from
+//                  becomes the fragment buffers, so a barrier separates the two uses.  Weights and h rows are requested
+//                  BEFORE that barrier (a wave that has finished its edge job has its registers free while the slower
+//                  waves finish theirs).  Waves >= NT help with the staging and retire.
+template <int H, bool FUSED, int SEGW>
+SM_DEV void chain16_body(const NodeChainArgs &a, int *range_flag, int first_atom, int ncols, const float4 (&keep)[H / 16]) {
     using L = Chain16Lds<H>;
     using N16 = Node16<H>;
     constexpr int NT = H / 16, NB = H / 32, CC = CHAIN_COLS;
@@ -182,32 +189,87 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
     float *pre0 = reinterpret_cast<float *>(fin + 3 * L::FRAG), *pre1 = pre0 + L::PRE;
     const int lane = threadIdx.x & 63, ot = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int ct0 = blockIdx.x * CC;
-    const int f0 = 16 * ot + 4 * g;
-    auto atom_of = [&](int c) { return min((ct0 + c) * 16 + n, a.n_atoms - 1); };
-    auto atom_ok = [&](int c) { return (ct0 + c) * 16 + n < a.n_atoms; };
+    const int f0 = 16 * (ot < NT ? ot : 0) + 4 * g;
+    auto atom_of = [&](int c) { return min(first_atom + c * 16 + n, a.n_atoms - 1); };
+    auto atom_ok = [&](int c) { return c * 16 + n < ncols && first_atom + c * 16 + n < a.n_atoms; };
 
     SM_TICK(a.stamps, 0);
     // ---- stage 0: weights of the output MLP; [att | h] tiles -> fragments ----------------------------
     u32x4 w1[2][2 * NB], w2[2][NB];
-    N16::template load_w<2 * NB>(a.w1img6, ot, lane, w1);
-    for (int idx = threadIdx.x; idx < CC * 2 * NB * 64; idx += NT * 64) {
-        const int sl = idx & 63, sb = (idx >> 6) % (2 * NB), sc = idx / (64 * 2 * NB);
-        const int at = min((ct0 + sc) * 16 + (sl & 15), a.n_atoms - 1);
-        const float *src = (sb < NB ? a.att + (size_t)at * H + 32 * sb : a.h + (size_t)at * H + 32 * (sb - NB)) + 4 * (sl >> 4);
-        const float4 v0 = ldg4(src), v1 = ldg4(src + 16);
-        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        u32x4 hi, lo;
-        split2_8(v, hi, lo, range_flag);
-        u32x4 *dst = fin + (sb * CC + sc) * 64 + frag_slot(sb, sl);
-        dst[0] = hi; dst[2 * NB * CC * 64] = lo;
-    }
-    N16::template load_w<NB>(a.w2img6, ot, lane, w2);
     float4 hres[CC];
+    float4 b1, b2;
+    if constexpr (!FUSED) {
+        N16::template load_w<2 * NB>(a.w1img6, ot, lane, w1);
+        for (int idx = threadIdx.x; idx < CC * 2 * NB * 64; idx += NT * 64) {
+            const int sl = idx & 63, sb = (idx >> 6) % (2 * NB), sc = idx / (64 * 2 * NB);
+            const int at = min(first_atom + sc * 16 + (sl & 15), a.n_atoms - 1);
+            const float *src = (sb < NB ? a.att + (size_t)at * H + 32 * sb : a.h + (size_t)at * H + 32 * (sb - NB)) + 4 * (sl >> 4);
+            const float4 v0 = ldg4(src), v1 = ldg4(src + 16);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            u32x4 hi, lo;
+            split2_8(v, hi, lo, range_flag);
+            u32x4 *dst = fin + (sb * CC + sc) * 64 + frag_slot(sb, sl);
+            dst[0] = hi; dst[2 * NB * CC * 64] = lo;
+        }
+        N16::template load_w<NB>(a.w2img6, ot, lane, w2);
 #pragma unroll
-    for (int c = 0; c < CC; ++c) hres[c] = ldg4(a.h + (size_t)atom_of(c) * H + f0);    // residual
-    const float4 b1 = ldg4(a.b1 + f0), b2 = ldg4(a.b2 + f0);
-    __syncthreads();
+        for (int c = 0; c < CC; ++c) hres[c] = ldg4(a.h + (size_t)atom_of(c) * H + f0);    // residual
+        b1 = ldg4(a.b1 + f0); b2 = ldg4(a.b2 + f0);
+        __syncthreads();
+    } else {
+        // requests first (they fly while the other waves finish their edge jobs) ...
+        const bool worker = ot < NT;
+        if (worker) {
+            N16::template load_w<2 * NB>(a.w1img6, ot, lane, w1);
+            N16::template load_w<NB>(a.w2img6, ot, lane, w2);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) hres[c] = ldg4(a.h + (size_t)atom_of(c) * H + f0);
+            b1 = ldg4(a.b1 + f0); b2 = ldg4(a.b2 + f0);
+        }
+        // h rows: CC * NB * 64 fragment items, one per thread of the first 8 waves' worth of threads
+        const int hidx = threadIdx.x;
+        const bool hstage = hidx < CC * NB * 64;
+        const int hsl = hidx & 63, hsb = (hidx >> 6) % NB, hsc = hidx / (64 * NB);
+        float4 hv0 = {0.f, 0.f, 0.f, 0.f}, hv1 = hv0;
+        if (hstage) {
+            const int at = min(first_atom + hsc * 16 + (hsl & 15), a.n_atoms - 1);
+            const float *src = a.h + (size_t)at * H + 32 * hsb + 4 * (hsl >> 4);
+            hv0 = ldg4(src); hv1 = ldg4(src + 16);
+        }
+        __syncthreads();                                     // every wave is done with the edge images
+        // ... the attention rows this wave holds -> fragments of its columns (the storing lanes)
+        if ((n % SEGW) == 0) {
+            const int col = ot * (16 / SEGW) + n / SEGW;
+            if (col < CC * 16) {
+#pragma unroll
+                for (int sb = 0; sb < NB; ++sb) {
+                    const float v[8] = {keep[2 * sb].x, keep[2 * sb].y, keep[2 * sb].z, keep[2 * sb].w,
+                                        keep[2 * sb + 1].x, keep[2 * sb + 1].y, keep[2 * sb + 1].z, keep[2 * sb + 1].w};
+                    u32x4 hi, lo;
+                    split2_8(v, hi, lo, range_flag);
+                    u32x4 *dst = fin + (sb * CC + (col >> 4)) * 64 + frag_slot(sb, g * 16 + (col & 15));
+                    dst[0] = hi; dst[2 * NB * CC * 64] = lo;
+                }
+            }
+        }
+        // columns beyond the workgroup's atoms: zero attention fragments
+        for (int idx = threadIdx.x; idx < CC * NB * 64; idx += blockDim.x) {
+            const int sl = idx & 63, sb = (idx >> 6) % NB, sc = idx / (64 * NB);
+            if (sc * 16 + (sl & 15) >= ncols) {
+                u32x4 *dst = fin + (sb * CC + sc) * 64 + frag_slot(sb, sl);
+                dst[0] = u32x4{0u, 0u, 0u, 0u}; dst[2 * NB * CC * 64] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        if (hstage) {
+            const float v[8] = {hv0.x, hv0.y, hv0.z, hv0.w, hv1.x, hv1.y, hv1.z, hv1.w};
+            u32x4 hi, lo;
+            split2_8(v, hi, lo, range_flag);
+            u32x4 *dst = fin + ((NB + hsb) * CC + hsc) * 64 + frag_slot(NB + hsb, hsl);
+            dst[0] = hi; dst[2 * NB * CC * 64] = lo;
+        }
+        __syncthreads();
+        if (!worker) return;
+    }
     SM_TICK(a.stamps, 1);
 
     // ---- stage 1: h' = h + W2 relu(LN(W1 [att | h] + b1)) + b2 ---------------------------------------
@@ -272,7 +334,7 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
     if (on1) N16::template load_w<NB>(a.f[1].w2img6, ot, lane, wg1);
     // per-node products of the next attentions: tiles ot, ot + NT, ... of [n_lin_tiles * 16][H], weights alternating between
     // two register sets so that the next block is in flight during the current product (as node_prologue16_kernel)
-    if (a.n_lin_tiles > 0) {
+    if (!FUSED && a.n_lin_tiles > 0) {
         u32x4 wl[2][NB];
         N16::template load_w<NB>(a.lin_img16, ot, lane, wl);
         auto lin_tile = [&](int tile, const u32x4 (&w)[2][NB]) {
@@ -326,6 +388,26 @@ node_chain16_kernel(NodeChainArgs a, int *range_flag) {
         }
     }
     SM_STAMP(a.stamps, 7);
+}
+
+template <int H>
+__global__ void __launch_bounds__(H * 4)
+node_chain16_kernel(NodeChainArgs a, int *range_flag) {
+    float4 keep[H / 16];
+    chain16_body<H, false, 8>(a, range_flag, blockIdx.x * CHAIN_COLS * 16, CHAIN_COLS * 16, keep);
+}
+
+// x2h attention and the node stage of the same layer in one launch (one job per wave, >= H / 16 waves per workgroup): the
+// attention rows of a workgroup's atoms never leave the CU, the node stage's first weights are requested while the slower
+// waves still finish their edge jobs, and one launch (with its ramp, drain and cache write-back) per layer disappears.
+template <int H, int KP>
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
+x2h_chain16_kernel(Edge16Args e, NodeChainArgs a, int *range_flag) {
+    float4 keep[H / 16];
+    edge16_body<H, KP, false, true, true>(e, keep);
+    const int nwave = blockDim.x >> 6, apj = 16 / KP;
+    const int first_atom = (e.job_base + blockIdx.x * nwave) * apj;
+    chain16_body<H, true, KP>(a, range_flag, first_atom, nwave * apj, keep);
 }
 
 template <int H>
