@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--concurrent", type=int, default=2,
                     help="also report the throughput of this many independent batch-256 chains run concurrently on the GPU "
                          "(extra field, never `value`; 0/1 = skip)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="context option for kernel experiments (shapemol_set_option), e.g. --opt x2h_chain=0; recorded in config")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,6 +128,9 @@ def main():
     sdn = synth.synthetic_state_dict(cfg, seed=7)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
     model = model.to(dev)
+    for kv in args.opt:
+        name, val = kv.split("=")
+        model.set_option(name, int(val))
     steps, warm = min(args.steps, CHAIN_STEPS), max(0, min(args.warmup, CHAIN_STEPS))
 
     bb = synth.synthetic_batch(args.batch, seed=2021 + rank, atoms_range=atoms_range)     # every rank owns a different batch
@@ -187,7 +192,7 @@ def main():
                    "batch_per_gpu": args.batch, "atoms_per_gpu": n_atoms, "total_atoms": total_atoms,
                    "noise": "device Philox", "trajectories": "kept in HBM" if not args.no_traj else "off",
                    "launch": "hipGraph replay" if use_graph else "eager", "parallelism": f"dp{world} (whole batches per rank)",
-                   "ranks_seen": (dist.get_world_size() if dist is not None else 1), "ms_per_step_by_rank": rank_ms,
+                   "ranks_seen": (dist.get_world_size() if dist is not None else 1), "ms_per_step_by_rank": rank_ms, **({"options": args.opt} if args.opt else {}),
                    "matrix_products": "edge and node MLPs: two-piece f16 operands (22 significand bits), three products per term, fp32 "
                                       "accumulate; everything else fp32 (options edge_bf16 = 1, node_f16 = 0: exactly split bf16 operands)"},
     }

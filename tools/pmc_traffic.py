@@ -13,6 +13,8 @@ CLASSES = [("edge_fused_kernel", "false", "edge_x2h"), ("edge_fused_kernel", "tr
 
 
 def classify(name):
+    if "x2h_chain16_kernel" in name:
+        return "edge_x2h_chain"
     m = re.search(r"edge(?:_fused|16|16x2)_kernel<\d+, \d+, (false|true)", name)      # third template argument: H2X
     if m:
         return "edge_h2x" if m.group(1) == "true" else "edge_x2h"
