@@ -472,6 +472,7 @@ struct shapemol_ctx {
     int vn_fold = 1;            // coordinate update of layer l in the prologue of the x2h kernel of layer l + 1 (needs max_mol_atoms)
     int max_mol_atoms = 0;      // largest molecule of the batches to come (option; 0 = unknown: no fold)
     int lin_fuse = 0;           // 1: per-node products of the next attentions inside node_chain16_kernel instead of a node_linear
+    int graph_fuse = 1;         // 1: kNN graph + edge weights in one launch (graph_kernel) when max_mol_atoms <= kGraphCap is known
     int x2h_chain = 1;          // 1: x2h attention and the node stage of a layer in one launch (x2h_chain16_kernel) when every wave has one job
                                 // launch (measured: 28.5 us against 15.3 + 11.1 us, eight dependent weight blocks per wave)
     int node_f16 = 1;           // node kernels on two-piece f16 operands (sm_node16.h) instead of exactly split bf16 (sm_node.h)
@@ -821,10 +822,18 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     } else {
         LAUNCH("embed", SMK(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
     }
-    LAUNCH("knn", SMK(knn_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x_in, c->mol_of, c->mol_off, n, g.knn, KP, c->nbr));
+    const bool graph_fused = c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap && KP <= 32;
+    if (graph_fused) {
+        GraphArgs ga{x_in, c->mol_span, n, g.knn, KP, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
+                     c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, c->status + ST_SPAN};
+        const int apb = kGraphWaves * (KP >= 16 ? 1 : 16 / KP);      // atoms per workgroup
+        if (KP == 8) LAUNCH("graph", SMK((graph_kernel<H, 8>), dim3((n + apb - 1) / apb), dim3(kGraphWaves * 64), 0, s, ga));
+        else if (KP == 16) LAUNCH("graph", SMK((graph_kernel<H, 16>), dim3((n + apb - 1) / apb), dim3(kGraphWaves * 64), 0, s, ga));
+        else LAUNCH("graph", SMK((graph_kernel<H, 32>), dim3((n + apb - 1) / apb), dim3(kGraphWaves * 64), 0, s, ga));
+    } else LAUNCH("knn", SMK(knn_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x_in, c->mol_of, c->mol_off, n, g.knn, KP, c->nbr));
     EdgeWeightArgs ea{x_in, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
                       c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, n * KP, KP};
-    {
+    if (!graph_fused) {
         const int tiles = (n * KP + 15) / 16;
         LAUNCH("edge_weight", SMK(edge_weight_kernel<H>, dim3((tiles + 3) / 4), dim3(256), 0, s, ea));
     }
@@ -1200,6 +1209,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     else if (k == "node_f16") c->node_f16 = value != 0;
     else if (k == "lin_fuse") c->lin_fuse = value != 0;
     else if (k == "x2h_chain") c->x2h_chain = value != 0;
+    else if (k == "graph_fuse") c->graph_fuse = value != 0;
     else if (k == "vn_fold") c->vn_fold = value != 0;
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "chain_bf16") c->chain_bf16 = (int)value;

@@ -436,6 +436,137 @@ __global__ void vn_apply_kernel(VnArgs a) {
     }
 }
 
+// kNN graph and edge weights in one launch (knn_kernel + edge_weight_kernel: the weights of an atom's slots need its own
+// neighbour list only).  One wave per atom: the molecule's span comes from the precomputed table (no mol_of -> mol_off
+// chase), every candidate's squared distance is computed once and published in an LDS row, the rank loop compares against
+// broadcast reads of that row (the two kernels re-read the coordinates of every atom of the molecule from global memory
+// for every comparison), the neighbour list reaches the weight stage through LDS, and the first Linear's weights are
+// staged in LDS once per workgroup (edge_weight_kernel: forty dependent-address global loads per lane).  Same arithmetic,
+// bit for bit: the distances, the tie rule (lower index first) and the fp32 MFMA sequence are those of the two kernels.
+// Molecules of up to kGraphCap atoms (the host falls back to the two kernels otherwise).
+constexpr int kGraphCap = 128;
+constexpr int kGraphWaves = 8;
+struct GraphArgs {
+    const float *x;
+    const int2 *mol_span;   // [N] first / one-past-last atom of the atom's molecule
+    int n_atoms, k, kp;
+    int *nbr;               // [N][KP]
+    const float *w1, *b1, *g, *be, *w2, *b2;   // edge-weight MLP (as EdgeWeightArgs)
+    float *ew;              // [N][KP]
+    int *span_flag;         // status flag raised if a molecule exceeds kGraphCap atoms (the max_mol_atoms hint was wrong)
+};
+template <int H, int KP>
+__global__ void __launch_bounds__(kGraphWaves * 64)
+graph_kernel(GraphArgs a) {
+    constexpr int NT = H / 16;
+    constexpr int APW = KP >= 16 ? 1 : 16 / KP;          // atoms per wave = the atoms of one 16-slot tile
+    constexpr int LPA = 64 / APW;                         // candidate lanes per atom
+    constexpr int NQ = kGraphCap / LPA;                   // candidate chunks per lane
+    constexpr int TPW = KP > 16 ? KP / 16 : 1;            // tiles per wave
+    __shared__ float w1s[H * 20];
+    __shared__ float dist[kGraphWaves][APW][kGraphCap];
+    __shared__ float xs[kGraphWaves][APW][kGraphCap][3];  // the molecule's coordinates (the weight stage's neighbours live there)
+    __shared__ int row[kGraphWaves][APW * KP];
+    __shared__ __attribute__((aligned(16))) float prm[4][H];        // b1 | gamma | beta | w2
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int sub = lane / LPA, l = lane % LPA;
+    const int i_raw = (blockIdx.x * kGraphWaves + wave) * APW + sub;
+    const bool valid = i_raw < a.n_atoms;
+    const int i = valid ? i_raw : a.n_atoms - 1;
+    const int2 span = a.mol_span[i];
+    for (int idx = threadIdx.x; idx < H * 20; idx += kGraphWaves * 64) w1s[idx] = a.w1[idx];
+    // the weight stage's small operands go through LDS as well (requested now: no L2 round trip behind the graph stage,
+    // and no registers held across it)
+    for (int idx = threadIdx.x; idx < 4 * H; idx += kGraphWaves * 64) {
+        const int which = idx / H, f = idx % H;
+        prm[which][f] = (which == 0 ? a.b1 : which == 1 ? a.g : which == 2 ? a.be : a.w2)[f];
+    }
+    const float b2 = a.b2[0];
+    const float *x = a.x;
+    const int s = span.x, cnt = min(span.y - span.x, kGraphCap), self = i - s;
+    if (span.y - span.x > kGraphCap && l == 0) *a.span_flag = 1;
+    const float xi = x[i * 3], yi = x[i * 3 + 1], zi = x[i * 3 + 2];
+    float dc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = l + LPA * q;
+        dc[q] = 0.f;
+        if (c < cnt) {
+            const int j = s + c;
+            const float xj = x[j * 3], yj = x[j * 3 + 1], zj = x[j * 3 + 2];
+            const float dx = xj - xi, dy = yj - yi, dz = zj - zi;
+            dc[q] = dist2_rounded(dx, dy, dz);
+            dist[wave][sub][c] = dc[q];
+            xs[wave][sub][c][0] = xj; xs[wave][sub][c][1] = yj; xs[wave][sub][c][2] = zj;
+        }
+    }
+    for (int sl = l; sl < KP; sl += LPA) row[wave][sub * KP + sl] = -1;
+    __syncthreads();                       // w1s staged; this wave's rows of distances written
+    int rank[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) rank[q] = 0;
+    for (int o = 0; o < cnt; ++o) {
+        const float d_o = dist[wave][sub][o];
+        const bool other = o != self;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = l + LPA * q;
+            rank[q] += other && (o != c) && (d_o < dc[q] || (d_o == dc[q] && o < c));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = l + LPA * q;
+        if (c < cnt && c != self && rank[q] < a.k) row[wave][sub * KP + rank[q]] = s + c;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (valid)
+        for (int sl = l; sl < KP; sl += LPA) a.nbr[(size_t)i * KP + sl] = row[wave][sub * KP + sl];
+    // ---- edge weights of the wave's slots: edge_weight_kernel's tile (column n = slot n of the wave's atoms) ----
+    float cen[5];
+    rbf_centres(g, cen);
+    const int atom0 = (blockIdx.x * kGraphWaves + wave) * APW;
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int slot = tt * 16 + n;                     // slot of the wave: atom slot / KP, neighbour slot % KP
+        const int asub = slot / KP;                       // which of the wave's atoms
+        const int ia_raw = atom0 + asub;
+        const bool in_range = ia_raw < a.n_atoms;
+        const int ia = in_range ? ia_raw : a.n_atoms - 1;
+        const int jraw = in_range ? row[wave][slot] : -1;
+        const bool ok = in_range && jraw >= 0;
+        // both ends from the LDS copy of the molecule (ia's own molecule starts at its span; lanes of the other atom of the
+        // wave read that atom's table): index of the centre and of the neighbour inside the molecule
+        const int s_a = __shfl(s, asub * LPA), self_a = __shfl(self, asub * LPA);
+        const int cj = ok ? jraw - s_a : self_a;
+        const float *pa = xs[wave][asub][self_a], *pj = xs[wave][asub][cj];
+        const float r0 = pa[0] - pj[0], r1 = pa[1] - pj[1], r2 = pa[2] - pj[2];
+        float rb[5];
+        rbf_dlayout(sqrtf(r0 * r0 + r1 * r1 + r2 * r2), cen, rb);
+        float hid[NT * 4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 b = ldg4(prm[0] + 16 * t + 4 * g);
+            f32x4 acc = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5) acc = mfma16(w1s[(16 * t + n) * 20 + 4 * s5 + g], rb[s5], acc);
+            hid[4 * t] = acc[0]; hid[4 * t + 1] = acc[1]; hid[4 * t + 2] = acc[2]; hid[4 * t + 3] = acc[3];
+        }
+        ln_relu_dlayout<NT>(hid, prm[1], prm[2], g);
+        float p = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 w = ldg4(prm[3] + 16 * t + 4 * g);
+            p += w.x * hid[4 * t] + w.y * hid[4 * t + 1] + w.z * hid[4 * t + 2] + w.w * hid[4 * t + 3];
+        }
+        p = sum_groups(p) + b2;
+        if (g == 0 && in_range) a.ew[(size_t)ia * KP + slot % KP] = ok ? 1.0f / (1.0f + expf(-p)) : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // DDPM posterior step (molopt_score_model.py:653-681): q_pos_posterior (:400-404) + noise,
 // log_softmax, index_to_log_onehot (:64-68), q_v_posterior (:377-385) with the uniform mixing

@@ -713,6 +713,25 @@ def test_fp16_range_guard_of_the_node_kernels():
     assert torch.isfinite(out["pred_ligand_h"]).all()
 
 
+def test_fused_launches_equal_separate_launches():
+    """The fused launches of a step (kNN graph + edge weights: graph_kernel; x2h attention + node stage:
+    x2h_chain16_kernel) run the same arithmetic in the same order as the kernels they replace: a chain with them is
+    bit-identical to a chain without."""
+    m = hip_model()
+    for B, seed, rng in ((48, 9, None), (10, 4, (40, 80))):      # MOSES-size molecules; larger ones (two candidate chunks per lane)
+        bb = synth.synthetic_batch(B, seed=seed, atoms_range=rng)
+        eps, u = hash_noise(len(bb["batch"]), 6, seed)
+        r1 = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], 6, eps, u)
+        for opt in ("graph_fuse", "x2h_chain"):
+            try:
+                m.set_option(opt, 0)
+                r0 = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], 6, eps, u)
+            finally:
+                m.set_option(opt, 1)
+            assert torch.equal(r1["v"], r0["v"]) and torch.equal(r1["pos"], r0["pos"]), opt
+            assert torch.equal(torch.stack(r1["pos_traj"]), torch.stack(r0["pos_traj"])), opt
+
+
 def test_folded_coordinate_update_equals_separate_launch():
     """The coordinate update of a layer folded into the next x2h kernel (chains, default) against the separate vn_apply
     launches: same chain to rounding; and a max_mol_atoms hint below the truth is reported, not silently wrong."""
