@@ -472,6 +472,8 @@ struct shapemol_ctx {
     int vn_fold = 1;            // coordinate update of layer l in the prologue of the x2h kernel of layer l + 1 (needs max_mol_atoms)
     int max_mol_atoms = 0;      // largest molecule of the batches to come (option; 0 = unknown: no fold)
     int lin_fuse = 0;           // 1: per-node products of the next attentions inside node_chain16_kernel instead of a node_linear
+    int ddpm_fold = 1;          // 1: the last layer's coordinate update inside the DDPM kernel (chains without guidance)
+    DdpmFold ddpm_vf{};         // ... handed from run_score to run_ddpm
     int graph_fuse = 1;         // 1: kNN graph + edge weights in one launch (graph_kernel) when max_mol_atoms <= kGraphCap is known
     int x2h_chain = 1;          // 1: x2h attention and the node stage of a layer in one launch (x2h_chain16_kernel) when every wave has one job
                                 // launch (measured: 28.5 us against 15.3 + 11.1 us, eight dependent weight blocks per wave)
@@ -917,6 +919,11 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                     pending = VnFold{c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, x_next,
                                      c->mol_span, c->status + ST_SPAN, 1};
                     vn_done = true;
+                } else if (fold && last && l == L - 1 && out_pos && c->ddpm_fold && c->g_points == 0 && C <= 16 && hd <= 16) {
+                    // ... or, for the last layer of a chain step, the DDPM kernel
+                    ea.xsum = c->xsum;
+                    c->ddpm_vf = DdpmFold{c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, out_pos, hd, 1};
+                    vn_done = true;
                 }
             }
             if (launch_edge16<H, true>(c, s, ea)) return 1;
@@ -964,6 +971,7 @@ int run_ddpm(shapemol_ctx *c, hipStream_t s, int64_t N) {
     a.cp = c->chain_params; a.step_cur = c->steps + 1; a.step_ptr = c->steps;
     a.x_next = c->x_state; a.v_next = c->v_state;
     a.n_atoms = (int)N; a.C = g.num_classes;
+    a.vf = c->ddpm_vf; c->ddpm_vf = DdpmFold{};
     if (c->stamp_on) LAUNCH("stamp", SMK(clock_stamp_kernel, dim3(1), dim3(64), 0, s, c->stamps, c->steps + 1, 1024));
     if (g.num_classes <= 16) LAUNCH("ddpm", SMK(ddpm_step16_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, s, a));
     else LAUNCH("ddpm", SMK(ddpm_step_kernel<32>, dim3((N + 127) / 128), dim3(128), 0, s, a));
@@ -1210,6 +1218,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     else if (k == "lin_fuse") c->lin_fuse = value != 0;
     else if (k == "x2h_chain") c->x2h_chain = value != 0;
     else if (k == "graph_fuse") c->graph_fuse = value != 0;
+    else if (k == "ddpm_fold") c->ddpm_fold = value != 0;
     else if (k == "vn_fold") c->vn_fold = value != 0;
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;
     else if (k == "chain_bf16") c->chain_bf16 = (int)value;

@@ -585,6 +585,18 @@ struct ChainParams {
 };
 __global__ void set_chain_params_kernel(ChainParams *dst, ChainParams v, int *step_counter) { *dst = v; *step_counter = v.step_base; }
 
+// The coordinate update of the LAST layer (vn_apply_kernel's work: batch-norm of ||p||, VN-leaky-ReLU, mean over the channels,
+// x += ...) inside the DDPM kernel: 16 lanes per atom there are the 16 channels here, and the predicted position is consumed
+// nowhere else (chains without guidance).  Same arithmetic as the update folded into the x2h kernels (sm_edge16.h, VnFold).
+struct DdpmFold {
+    const float *pd;          // [N][heads][6]
+    const double *acc;        // [kBnReplicas][2][heads] batch sums of the last layer
+    const float *bn_g, *bn_b; // [heads]
+    const float *xsum;        // [N][3] sum over the attention rows (h2x epilogue)
+    const float *x_old;       // [N][3]
+    float *pred_out;          // [N][3] the predicted position (kept for readers of the score's output)
+    int heads, enable;
+};
 struct DdpmArgs {
     const float *pred_pos;   // [N][3]
     const float *pred_v;     // [N][C]
@@ -599,6 +611,7 @@ struct DdpmArgs {
     float *x_next;           // [N][3]
     int64_t *v_next;         // [N]
     int n_atoms, C;
+    DdpmFold vf;             // ddpm_step16_kernel only
 };
 template <int MAXC>
 __global__ void ddpm_step_kernel(DdpmArgs aa) {
@@ -716,9 +729,51 @@ __global__ void __launch_bounds__(256) ddpm_step16_kernel(DdpmArgs aa) {
         ph((uint32_t)i, (uint32_t)step, (uint32_t)(1 + (c >> 2)), 0x5eedu, r);
         uu = u01_half(r[c & 3]);
     }
+    // ---- predicted position: given, or the last layer's coordinate update done here (lane = channel)
+    float pp_fold = 0.f;
+    if (a.vf.enable) {
+        __shared__ double sred[32];
+        const int HD = a.vf.heads;
+        if (threadIdx.x < 32) {
+            const int cc = threadIdx.x & 15, which = threadIdx.x >> 4;
+            double t = 0.0;
+            if (cc < HD) for (int r = 0; r < kBnReplicas; ++r) t += a.vf.acc[(size_t)r * 2 * HD + which * HD + cc];
+            sred[threadIdx.x] = t;
+        }
+        __syncthreads();
+        float o[3] = {0.f, 0.f, 0.f};
+        if (c < HD) {
+            const double cnt = (double)a.n_atoms;
+            const double mean = sred[c] / cnt;
+            double var = sred[16 + c] / cnt - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float meanf = (float)mean;
+            const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+            const float *pdp = a.vf.pd + ((size_t)i * HD + c) * 6;
+            float p[3] = {pdp[0], pdp[1], pdp[2]};
+            const float d[3] = {pdp[3], pdp[4], pdp[5]};
+            const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
+            const float nbn = (nrm - meanf) * rstd * a.vf.bn_g[c] + a.vf.bn_b[c];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[k] = p[k] / nrm * nbn;
+            const float dot = p[0] * d[0] + p[1] * d[1] + p[2] * d[2];
+            const float dsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const float coef = dot / (dsq + 1e-6f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[k] = 0.2f * p[k] + 0.8f * (dot >= 0.f ? p[k] : p[k] - coef * d[k]);
+        }
+        float res[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) res[k] = seg_sum<16>(o[k]);              // over the channels of the atom
+        if (c < 3) {
+            const float r = c == 0 ? res[0] : (c == 1 ? res[1] : res[2]);
+            pp_fold = a.vf.x_old[i * 3 + c] + (a.vf.xsum[i * 3 + c] / HD + r / HD);
+            if (atom_ok) a.vf.pred_out[i * 3 + c] = pp_fold;
+        }
+    }
     // ---- positions (lanes 0..2)
     if (c < 3) {
-        const float pp = a.pred_pos[i * 3 + c];
+        const float pp = a.vf.enable ? pp_fold : a.pred_pos[i * 3 + c];
         const float sig = t != 0 ? expf(0.5f * a.logvar[t]) : 0.f;
         const float xn = (a.c0[t] * pp + a.ct[t] * a.x_t[i * 3 + c]) + sig * eps;
         if (atom_ok) {
