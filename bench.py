@@ -255,7 +255,7 @@ def main():
             "note": "achieved: fp32 FLOPs of the kernel's algorithm (factorised first Linears) per second; peak: the dense f16 MFMA peak "
                     "(2.5 PFLOP/s) / 3, because each fp32 product is evaluated as three f16 piece products (22-bit operands, fp32 "
                     "accumulate) -- frac_of_fp32_mfma_peak compares the same rate with the 157.3 TFLOP/s fp32 matrix peak it no longer uses. "
-                    "The step is latency-bound (about 44 dependent launches of 5-20 us on 5.5k atoms), not bound by either roof: "
+                    "The step is latency-bound (27 dependent launches of 7-31 us on 5.5k atoms at B = 256), not bound by either roof: "
                     "hbm_frac = PMC HBM bytes per launch / launch time / 8 TB/s, matrix_pipe_frac = f16/bf16 piece-product FLOPs "
                     "actually issued / 2.5 PFLOP/s, step_frac = executed fp32 FLOPs of the whole step / step time / fp32 peak",
             "step_tflops_executed": round(step_exec, 3),
