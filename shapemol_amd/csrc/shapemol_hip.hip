@@ -593,7 +593,8 @@ bool vn_fold_ok(const shapemol_ctx *c, int n_atoms) {
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
     if (c->edge_threads > 0) return false;                                 // wave-count sweeps: keep the plain path
     if (njobs > grid * waves && c->edge_tiles != 0) return false;         // looping launches: a workgroup's jobs are not contiguous
-    return waves * apj + 2 * (c->max_mol_atoms - 1) <= kVnFoldCap;
+    const int waves_max = std::max(waves, c->cfg.hidden_dim / 16);          // the fused x2h + node-stage launch never uses fewer
+    return waves_max * apj + 2 * (c->max_mol_atoms - 1) <= kVnFoldCap;
 }
 
 template <int H>
@@ -721,6 +722,8 @@ bool x2h_chain_ok(const shapemol_ctx *c, int n_atoms) {
     const int apj = 16 / c->KP, njobs = (n_atoms + apj - 1) / apj;
     const int waves = std::max(H / 16, edge_waves_for(c, njobs));
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
+    // one launch only: in slices (larger batches) the fused kernel loses to the separate ones, whose node stage then has
+    // enough atoms per launch to run at its throughput (B = 1024: 523 against 538 molecules/s)
     return waves <= 12 && waves * apj <= CHAIN_COLS * 16 && njobs <= grid * waves && Chain16Lds<H>::BYTES <= 2 * EdgeImage16<H, H / 16>::TOTAL * 4;
 }
 
