@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SHAPEMOL_ABI_VERSION 2
+#define SHAPEMOL_ABI_VERSION 3
 
 typedef struct shapemol_ctx shapemol_ctx;
 
@@ -127,6 +127,15 @@ int shapemol_guide_points(shapemol_ctx *ctx, float *d_pos, int64_t n_points, con
  * The reference raises from the corresponding torch indexing ops (models/molopt_score_model.py:292-301). */
 int shapemol_status(shapemol_ctx *ctx, int32_t *flags_out);
 
+/* Evaluation-mode batch-norm (the module after .eval(): scripts/train_diffusion.py:172-173 puts it there for validate(),
+ * models/shape_vn_layers.py:50-61 then normalises the vector norms with BatchNorm1d's running statistics instead of the
+ * batch's).  h_mean, h_var: HOST [num_layers][n_heads] float32, the buffers
+ * refine_net.base_block.{l}.h2x_layers.0.shape_linear.batchnorm.bn.running_{mean,var}; count = num_layers * n_heads.
+ * Takes effect with shapemol_set_option(ctx, "bn_eval", 1); training mode (the default, and what sampling uses: the
+ * reference never leaves it while sampling) keeps using the statistics of the batch.  The running statistics
+ * are read, never updated (no training step on this path). */
+int shapemol_set_bn_running(shapemol_ctx *ctx, const float *h_mean, const float *h_var, int64_t count);
+
 /* argmax_c( logits[n,c] - log(-log(u[n,c] + 1e-30) + 1e-30) ); d_u NULL -> device Philox(seed). */
 int shapemol_log_sample_categorical(shapemol_ctx *ctx, const float *d_logits, const float *d_u,
                                     int64_t n_rows, int32_t n_classes, uint64_t seed,
@@ -174,7 +183,15 @@ int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_sh
  *          "vn_fuse"    (2 = VN-linear + batch-norm statistics in the epilogue of the h2x attention, vn_apply as its
  *                        own launch [default]; 1 = the whole coordinate update behind h2x with an in-kernel grid
  *                        barrier (no faster: measured); 0 = separate vn_stats / vn_apply launches),
- *          "edge_waves" (waves per workgroup of the edge kernels, 1..12; 0 = automatic: ceil(jobs / CUs) [default]),
+ *          "bn_eval"    (1 = evaluation-mode batch-norm: the running statistics of shapemol_set_bn_running; 0 = the
+ *                        statistics of the batch [default, and what the reference's sampling runs with]),
+ *          "x2h_chain"  (1 = x2h attention and node stage of a layer in one launch when every wave has one job in a
+ *                        single launch (up to ~6k atoms) [default], 0 = separate launches),
+ *          "graph_fuse" (1 = kNN graph + edge weights in one launch when max_mol_atoms is known and <= 128 [default]),
+ *          "ddpm_fold"  (_sample only: 1 = the last layer's coordinate update inside the posterior-step kernel when the
+ *                        fold above applies and no guidance is set [default]),
+ *          "edge_waves" (waves per workgroup of the edge kernels, 1..12; 0 = automatic: ceil(jobs / CUs) [default]; a
+ *                        value other than 0 also selects the separate launches),
  *          "lin_waves"  (1..16 waves per workgroup of node_linear_kernel, tuning),
  *          "stamps", "kstamp_sel" (clock-stamp diagnostics; only meaningful in the --stamps build).
  * Changing an option invalidates a captured graph (the next _sample re-captures). */

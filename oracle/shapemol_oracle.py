@@ -152,14 +152,18 @@ def _x2h(sd, p, dm, h, rfeat, src, dst, inv_atom, e_w):
     return _mlp(sd, p + ".node_output", torch.cat([o, h], -1)) + h
 
 
-def _vn_linear_lrelu(sd, p, z, taps=None):
-    """z: (N, Cin, 3) -> (N, Cout, 3); vector-neuron linear, train-mode batch norm of the
-    vector norms (biased variance over all N atoms, eps 1e-5, affine), VN leaky ReLU."""
+def _vn_linear_lrelu(sd, p, z, taps=None, bn_eval=False):
+    """z: (N, Cin, 3) -> (N, Cout, 3); vector-neuron linear, batch norm of the vector norms (train mode: biased variance
+    over all N atoms; bn_eval: the running statistics, as BatchNorm1d in eval mode -- shape_vn_layers.py:50-61 under
+    module.eval()), eps 1e-5, affine, VN leaky ReLU."""
     wf, wd = sd[p + ".map_to_feat.weight"], sd[p + ".map_to_dir.weight"]
     pf = torch.einsum("oc,ncd->nod", wf, z)
     nrm = torch.sqrt((pf * pf).sum(2)) + VN_EPS
-    mean = nrm.mean(0)
-    var = ((nrm - mean) ** 2).mean(0)
+    if bn_eval:
+        mean, var = sd[p + ".batchnorm.bn.running_mean"], sd[p + ".batchnorm.bn.running_var"]
+    else:
+        mean = nrm.mean(0)
+        var = ((nrm - mean) ** 2).mean(0)
     if taps is not None:
         taps["bn_mean"], taps["bn_var"], taps["bn_in"] = mean, var, nrm
     nbn = (nrm - mean) / torch.sqrt(var + 1e-5) * sd[p + ".batchnorm.bn.weight"] + sd[p + ".batchnorm.bn.bias"]
@@ -171,7 +175,7 @@ def _vn_linear_lrelu(sd, p, z, taps=None):
     return LEAK * pf + (1 - LEAK) * (mask * pf + (1 - mask) * (pf - (dot / (dsq + VN_EPS)) * d))
 
 
-def _h2x(sd, p, dm, h, x, rel_x, rfeat, src, dst, inv_atom, shape_atom, e_w, taps=None):
+def _h2x(sd, p, dm, h, x, rel_x, rfeat, src, dst, inv_atom, shape_atom, e_w, taps=None, bn_eval=False):
     n = h.shape[0]
     kv = torch.cat([rfeat, h[dst], h[src], inv_atom[dst]], -1)
     k = _mlp(sd, p + ".xk_func", kv)
@@ -181,11 +185,11 @@ def _h2x(sd, p, dm, h, x, rel_x, rfeat, src, dst, inv_atom, shape_atom, e_w, tap
     alpha = _attention(q, k, dst, n, dm.heads)
     o = _segment_sum(alpha.unsqueeze(-1) * v, dst, n)                      # (N, heads, 3)
     z = torch.cat((x.unsqueeze(1), o, shape_atom), dim=1)                   # (N, 1+heads+S, 3)
-    res = _vn_linear_lrelu(sd, p + ".shape_linear", z, taps).mean(dim=1)
+    res = _vn_linear_lrelu(sd, p + ".shape_linear", z, taps, bn_eval).mean(dim=1)
     return o.mean(dim=1) + res
 
 
-def _refine(sd, dm, h, x, batch, shape, taps=None):
+def _refine(sd, dm, h, x, batch, shape, taps=None, bn_eval=False):
     inv_atom = _invariant_shape(sd, shape)[batch]
     shape_atom = shape[batch]
     src, dst = knn_edges(x, batch, dm.k)
@@ -199,7 +203,7 @@ def _refine(sd, dm, h, x, batch, shape, taps=None):
         rfeat = _rbf(torch.norm(rel_x, p=2, dim=-1, keepdim=True))
         h = _x2h(sd, p + ".x2h_layers.0", dm, h, rfeat, src, dst, inv_atom, e_w)
         lt = {} if taps is not None else None
-        dx = _h2x(sd, p + ".h2x_layers.0", dm, h, x, rel_x, rfeat, src, dst, inv_atom, shape_atom, e_w, lt)
+        dx = _h2x(sd, p + ".h2x_layers.0", dm, h, x, rel_x, rfeat, src, dst, inv_atom, shape_atom, e_w, lt, bn_eval)
         x = x + dx
         if taps is not None:
             taps[f"h_{l}"], taps[f"dx_{l}"] = h, dx
@@ -208,13 +212,14 @@ def _refine(sd, dm, h, x, batch, shape, taps=None):
 
 
 @torch.no_grad()
-def score(sd, dm, pos, v, batch, shape, t, taps=None):
+def score(sd, dm, pos, v, batch, shape, t, taps=None, bn_eval=False):
     """One score evaluation.  pos (N,3) f32, v (N,) i64, batch (N,) i64 sorted, shape (B,S,3)
-    f32, t (B,) i64 -> dict(pred_ligand_pos (N,3), pred_ligand_h (N,H), pred_ligand_v (N,C))."""
+    f32, t (B,) i64 -> dict(pred_ligand_pos (N,3), pred_ligand_h (N,H), pred_ligand_v (N,C)).
+    bn_eval: the module after .eval() (running batch-norm statistics)."""
     onehot = F.one_hot(v, dm.C).float()
     feat = torch.cat([onehot, _time_embedding(sd, dm, t)[batch]], -1)
     h = _lin(sd, "ligand_atom_emb", feat)
-    h, x = _refine(sd, dm, h, pos, batch, shape, taps)
+    h, x = _refine(sd, dm, h, pos, batch, shape, taps, bn_eval)
     hv = F.softplus(_lin(sd, "v_inference.0", h)) - math.log(2.0)
     return {"pred_ligand_pos": x, "pred_ligand_h": h, "pred_ligand_v": _lin(sd, "v_inference.2", hv)}
 
@@ -256,6 +261,60 @@ def posterior_step(sd, dm, pos, v, pred_pos, pred_v, batch, t, eps, u):
     un = a + b
     log_post = un - torch.logsumexp(un, dim=-1, keepdim=True)
     return pos_next, gumbel_argmax(log_post, u), log_v0, log_post
+
+
+def _v_posterior(sd, dm, log_v0, log_vt, t, batch):
+    """q(v_{t-1} | v_t, v_0) in log space (molopt_score_model.py:377-385)."""
+    tb = t[batch]
+    tm1 = torch.where(t - 1 < 0, torch.zeros_like(t), t - 1)[batch]
+    a = _mix_uniform(log_v0, sd["log_alphas_cumprod_v"][tm1].unsqueeze(-1),
+                     sd["log_one_minus_alphas_cumprod_v"][tm1].unsqueeze(-1), dm.C)
+    b = _mix_uniform(log_vt, sd["log_alphas_v"][tb].unsqueeze(-1),
+                     sd["log_one_minus_alphas_v"][tb].unsqueeze(-1), dm.C)
+    un = a + b
+    return un - torch.logsumexp(un, dim=-1, keepdim=True)
+
+
+def _scatter_mean(val, batch, n_mols):
+    out = torch.zeros((n_mols,) + val.shape[1:], dtype=val.dtype).index_add_(0, batch, val)
+    cnt = torch.zeros(n_mols, dtype=val.dtype).index_add_(0, batch, torch.ones_like(batch, dtype=val.dtype)).clamp(min=1)
+    return out / cnt.view(-1, *([1] * (val.dim() - 1)))
+
+
+@torch.no_grad()
+def diffusion_loss(sd, dm, pos, v, batch, shape, t, pos_noise, u, bn_eval=True, loss_v_weight=100.0, loss_weight_type="noise_level"):
+    """get_diffusion_loss with eval_mode=True and given time steps (molopt_score_model.py:447-531; the form validate() of
+    scripts/train_diffusion.py:168-192 calls, module in eval mode): perturb positions and atom types at t (pos_noise (N,3)
+    is the normal_() draw of :461, u (N,C) the rand_like of log_sample_categorical inside q_v_sample :366-374), one score
+    evaluation, position MSE per molecule weighted by loss_pos_step_weight[t] (:506-518), atom-type KL / decoder NLL
+    (compute_v_Lt :436-445).  center_pos_mode = none, v_mode = uniform (the shipped training configuration)."""
+    n_mols = shape.shape[0]
+    a_pos = sd["alphas_cumprod"][t][batch].unsqueeze(-1)
+    pos_pert = a_pos.sqrt() * pos + (1.0 - a_pos).sqrt() * pos_noise
+    log_v0 = torch.log(F.one_hot(v, dm.C).float().clamp(min=1e-30))
+    tb = t[batch]
+    log_qvt = _mix_uniform(log_v0, sd["log_alphas_cumprod_v"][tb].unsqueeze(-1),
+                           sd["log_one_minus_alphas_cumprod_v"][tb].unsqueeze(-1), dm.C)
+    v_pert = gumbel_argmax(log_qvt, u)
+    log_vt = torch.log(F.one_hot(v_pert, dm.C).float().clamp(min=1e-30))
+    out = score(sd, dm, pos_pert, v_pert, batch, shape, t, bn_eval=bn_eval)
+    pred_pos, pred_v = out["pred_ligand_pos"], out["pred_ligand_v"]
+    log_recon = F.log_softmax(pred_v, dim=-1)
+    log_model = _v_posterior(sd, dm, log_recon, log_vt, t, batch)
+    log_true = _v_posterior(sd, dm, log_v0, log_vt, t, batch)
+    kl = (log_true.exp() * (log_true - log_model)).sum(dim=1)
+    nll = -(log_v0.exp() * log_model).sum(dim=1)
+    mask = (t == 0).float()[batch]
+    kl_v = _scatter_mean(mask * nll + (1.0 - mask) * kl, batch, n_mols)
+    loss_pos = _scatter_mean(((pred_pos - pos) ** 2).sum(-1), batch, n_mols)
+    if loss_weight_type == "noise_level":
+        loss_pos = torch.mean(sd["loss_pos_step_weight"][t] * loss_pos)
+    else:
+        loss_pos = torch.mean(loss_pos)
+    loss_v = torch.mean(kl_v)
+    return {"loss_pos": loss_pos, "loss_v": loss_v, "loss": loss_pos + loss_v * loss_v_weight, "x0": pos,
+            "ligand_pos_perturbed": pos_pert, "ligand_v_perturbed": v_pert, "pred_ligand_pos": pred_pos,
+            "pred_ligand_v": pred_v, "ligand_v_recon": F.softmax(pred_v, dim=-1)}
 
 
 @torch.no_grad()

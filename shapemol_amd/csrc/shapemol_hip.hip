@@ -472,6 +472,9 @@ struct shapemol_ctx {
     int vn_fold = 1;            // coordinate update of layer l in the prologue of the x2h kernel of layer l + 1 (needs max_mol_atoms)
     int max_mol_atoms = 0;      // largest molecule of the batches to come (option; 0 = unknown: no fold)
     int lin_fuse = 0;           // 1: per-node products of the next attentions inside node_chain16_kernel instead of a node_linear
+    int bn_eval = 0;            // 1: evaluation-mode batch-norm (running statistics, shapemol_set_bn_running) instead of the batch's
+    float *bn_run = nullptr;    // [2][L][heads] running mean | running variance (device)
+    double *bn_eval_acc = nullptr;   // [L][kBnReplicas][2][heads] sums that reproduce them for the current batch size
     int ddpm_fold = 1;          // 1: the last layer's coordinate update inside the DDPM kernel (chains without guidance)
     DdpmFold ddpm_vf{};         // ... handed from run_score to run_ddpm
     int graph_fuse = 1;         // 1: kNN graph + edge weights in one launch (graph_kernel) when max_mol_atoms <= kGraphCap is known
@@ -853,6 +856,15 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         if (launch_mlp2<H, 1>(c, s, "node_q", D0.q_x2h, cur_h, nullptr, NODE_LN_RELU, nullptr, c->q_x, H, H, n)) return 1;
     }
     const bool fold = sampling && vn_fold_ok(c, n);       // chains only: coordinate update of layer l inside the x2h kernel of layer l + 1
+    // evaluation-mode batch-norm: the consumers of the batch sums read sums that reproduce the running statistics
+    double *stat_acc = c->bn_acc;
+    if (c->bn_eval) {
+        if (!c->bn_run) return fail("bn_eval = 1 needs the running statistics (shapemol_set_bn_running)");
+        if (c->vn_fuse == 1) return fail("bn_eval = 1 is not available with vn_fuse = 1 (coordinate update behind a grid barrier)");
+        const int tot = L * kBnReplicas * 2 * hd;
+        LAUNCH("prep", SMK(bn_eval_fill_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, c->bn_run, c->bn_run + (size_t)L * hd, L, hd, n, c->bn_eval_acc));
+        stat_acc = c->bn_eval_acc;
+    }
     VnFold pending{};                         // ... which then receives this
     for (int l = 0; l < nlay; ++l) {
         const DevLayer &Dl = c->dm.layer[l];
@@ -919,13 +931,13 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                 stats_done = true;
                 if (fold && has_next) {      // no vn_apply launch: the next x2h kernel finishes the update
                     ea.xsum = c->xsum;
-                    pending = VnFold{c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, x_next,
+                    pending = VnFold{c->pd, stat_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, x_next,
                                      c->mol_span, c->status + ST_SPAN, 1};
                     vn_done = true;
                 } else if (fold && last && l == L - 1 && out_pos && c->ddpm_fold && c->g_points == 0 && C <= 16 && hd <= 16) {
                     // ... or, for the last layer of a chain step, the DDPM kernel
                     ea.xsum = c->xsum;
-                    c->ddpm_vf = DdpmFold{c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, out_pos, hd, 1};
+                    c->ddpm_vf = DdpmFold{c->pd, stat_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, out_pos, hd, 1};
                     vn_done = true;
                 }
             }
@@ -951,6 +963,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         const int per_blk = 256 / hd;
         if (!vn_done) {
             if (!stats_done) LAUNCH("vn_stats", SMK(vn_stats_kernel, dim3((N + per_blk - 1) / per_blk), dim3(kVnThreads), 0, s, va));
+            if (c->bn_eval) va.acc = stat_acc + (size_t)l * kBnReplicas * 2 * hd;      // (the statistics pass wrote the batch's sums elsewhere)
             LAUNCH("vn_apply", SMK(vn_apply_kernel, dim3((N + per_blk - 1) / per_blk), dim3(256), 0, s, va));
         }
         cur_x = x_next;
@@ -1090,7 +1103,26 @@ void shapemol_destroy(shapemol_ctx *c) {
     hipFree(c->ttab);
     hipFree(c->d_img);
     if (c->g_cloud) hipFree(c->g_cloud);
+    if (c->bn_run) hipFree(c->bn_run);
+    if (c->bn_eval_acc) hipFree(c->bn_eval_acc);
     delete c;
+}
+
+int shapemol_set_bn_running(shapemol_ctx *c, const float *h_mean, const float *h_var, int64_t count) {
+    if (!c || !h_mean || !h_var) return fail("shapemol_set_bn_running: null argument");
+    const int L = c->cfg.num_layers, hd = c->cfg.n_heads;
+    if (count != (int64_t)L * hd) return fail("shapemol_set_bn_running: count must be num_layers * n_heads");
+    for (int64_t i = 0; i < count; ++i)
+        if (!(h_var[i] >= 0.f) || !std::isfinite(h_mean[i]) || !std::isfinite(h_var[i])) return fail("shapemol_set_bn_running: statistics must be finite, variance >= 0");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (!c->bn_run) {
+        HIPCHK(hipMalloc(&c->bn_run, 2 * count * sizeof(float)));
+        HIPCHK(hipMalloc(&c->bn_eval_acc, (size_t)L * kBnReplicas * 2 * hd * sizeof(double)));
+    }
+    HIPCHK(hipMemcpy(c->bn_run, h_mean, count * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->bn_run + count, h_var, count * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
 }
 
 int shapemol_reserve(shapemol_ctx *c, int64_t max_atoms, int64_t max_mols) {
@@ -1221,6 +1253,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     else if (k == "lin_fuse") c->lin_fuse = value != 0;
     else if (k == "x2h_chain") c->x2h_chain = value != 0;
     else if (k == "graph_fuse") c->graph_fuse = value != 0;
+    else if (k == "bn_eval") c->bn_eval = value != 0;
     else if (k == "ddpm_fold") c->ddpm_fold = value != 0;
     else if (k == "vn_fold") c->vn_fold = value != 0;
     else if (k == "lin_bf16") c->lin_bf16 = (int)value;

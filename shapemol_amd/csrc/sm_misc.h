@@ -393,6 +393,23 @@ __global__ void __launch_bounds__(kVnThreads) vn_stats_kernel(VnArgs a) {
     }
 }
 
+// Evaluation-mode batch-norm (module.eval(): the running statistics instead of the batch's, shape_vn_layers.py:50-61 with
+// BatchNorm1d in eval mode): the consumers of the batch sums (VnFold, DdpmFold, vn_apply_kernel) take mean and variance
+// from sums over the batch, so they are handed sums that reproduce the running statistics for this batch size:
+// s1 = mean N, s2 = (var + mean^2) N in replica 0, zeros elsewhere (double: mean and var come back to the last float bit).
+__global__ void bn_eval_fill_kernel(const float *run_mean, const float *run_var, int n_layers, int heads, int n_atoms, double *acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = kBnReplicas * 2 * heads;
+    if (i >= n_layers * per) return;
+    const int l = i / per, r = (i % per) / (2 * heads), which = (i % (2 * heads)) / heads, c = i % heads;
+    double v = 0.0;
+    if (r == 0) {
+        const double m = (double)run_mean[l * heads + c], var = (double)run_var[l * heads + c];
+        v = which == 0 ? m * (double)n_atoms : (var + m * m) * (double)n_atoms;
+    }
+    acc[i] = v;
+}
+
 __global__ void vn_apply_kernel(VnArgs a) {
     __shared__ float red[256][3];
     const int heads = a.heads, per_blk = 256 / heads;

@@ -111,7 +111,15 @@ class ScorePosNet3D(nn.Module):
 
     # ------------------------------------------------------------------ library context
     def _weights_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters()) \
+            + tuple((b.data_ptr(), b._version) for n, b in self.named_buffers() if n.endswith(("running_mean", "running_var")))
+
+    def _bn_running(self):
+        """(mean, var) float32 [L][heads]: the batch-norm running statistics of the coordinate updates, layer by layer."""
+        sd = self.state_dict()
+        key = "refine_net.base_block.{}.h2x_layers.0.shape_linear.batchnorm.bn.running_{}"
+        take = lambda which: np.ascontiguousarray(np.stack([sd[key.format(l, which)].detach().cpu().numpy() for l in range(self.dims.L)]), np.float32)
+        return take("mean"), take("var")
 
     def _context(self, device):
         """Create (or refresh after a weight change / device move) the library context."""
@@ -130,8 +138,20 @@ class ScorePosNet3D(nn.Module):
         index = device.index if device.index is not None else torch.cuda.current_device()
         _lib.check(lib.shapemol_create(C.byref(cfg), packed.ctypes.data_as(C.c_void_p), packed.size, index, C.byref(ctx)),
                    "shapemol_create")
-        self._ctx, self._ctx_key = ctx, key
+        mean, var = self._bn_running()
+        _lib.check(lib.shapemol_set_bn_running(ctx, mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p), mean.size),
+                   "shapemol_set_bn_running")
+        self._ctx, self._ctx_key, self._bn_eval_set = ctx, key, False
         return ctx
+
+    def _sync_bn_mode(self, ctx):
+        """module.eval() / .train() -> the library's batch-norm mode (running statistics / the batch's), as nn.BatchNorm1d
+        switches with the module's flag (models/shape_vn_layers.py:45-61).  Sampling in the reference runs in train mode
+        (the scripts never call .eval() before sample_diffusion); validate() switches to eval."""
+        want = not self.training
+        if want != getattr(self, "_bn_eval_set", False):
+            _lib.check(_lib.load().shapemol_set_option(ctx, b"bn_eval", int(want)), "shapemol_set_option")
+            self._bn_eval_set = want
 
     def _release(self):
         if getattr(self, "_ctx", None) is not None:
@@ -175,6 +195,7 @@ class ScorePosNet3D(nn.Module):
             raise ValueError("inconsistent input shapes")
         dev = pos.device
         ctx = self._context(dev)
+        self._sync_bn_mode(ctx)
         out_pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
         out_h = torch.empty((n, self.dims.H), dtype=torch.float32, device=dev)
         out_v = torch.empty((n, self.dims.C), dtype=torch.float32, device=dev)
@@ -185,6 +206,96 @@ class ScorePosNet3D(nn.Module):
         _lib.check(rc, "shapemol_score")
         self._pending_check = True      # device-side input flags are read at the next check_status()
         return {"pred_ligand_pos": out_pos, "pred_ligand_h": out_h, "pred_ligand_v": out_v}
+
+    # ------------------------------------------------------------------ validation loss
+    def sample_time(self, num_graphs, device):
+        """Symmetric time sampling (models/molopt_score_model.py:415-422)."""
+        time_step = torch.randint(0, self.num_timesteps, size=(num_graphs // 2 + 1,), device=device)
+        time_step = torch.cat([time_step, self.num_timesteps - time_step - 1], dim=0)[:num_graphs]
+        return time_step, torch.ones_like(time_step).float() / self.num_timesteps
+
+    def _table(self, name):
+        return self.state_dict()[name]
+
+    def _v_mix(self, log_x, log_keep, log_drop):
+        a, b = log_x + log_keep, log_drop - float(np.log(self.num_classes))
+        m = torch.max(a, b)
+        return m + torch.log(torch.exp(a - m) + torch.exp(b - m))
+
+    def _q_v_posterior(self, log_v0, log_vt, t, batch):
+        tm1 = torch.where(t - 1 < 0, torch.zeros_like(t), t - 1)[batch]
+        tb = t[batch]
+        un = self._v_mix(log_v0, self._table("log_alphas_cumprod_v")[tm1].unsqueeze(-1), self._table("log_one_minus_alphas_cumprod_v")[tm1].unsqueeze(-1)) \
+            + self._v_mix(log_vt, self._table("log_alphas_v")[tb].unsqueeze(-1), self._table("log_one_minus_alphas_v")[tb].unsqueeze(-1))
+        return un - torch.logsumexp(un, dim=-1, keepdim=True)
+
+    @staticmethod
+    def _scatter_mean(val, batch, n_mols):
+        out = torch.zeros((n_mols,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device).index_add_(0, batch, val)
+        cnt = torch.bincount(batch, minlength=n_mols).clamp(min=1).to(val.dtype)
+        return out / cnt.view(-1, *([1] * (val.dim() - 1)))
+
+    def get_diffusion_loss(self, ligand_pos, ligand_v, batch_ligand, ligand_shape=None, time_step=None, eval_mode=False, *,
+                           noise=None):
+        """The reference's loss evaluation (models/molopt_score_model.py:447-531): perturb positions and atom types at
+        ``time_step`` (sampled symmetrically if None), one score evaluation on the device, position MSE and atom-type KL
+        per molecule.  Same arguments and result dict.  This is the form validate() runs (scripts/train_diffusion.py:168-192,
+        under torch.no_grad() with the module in eval mode, which switches the batch-norm to its running statistics);
+        gradients are NOT available on this path -- a call with autograd enabled raises instead of returning a loss that
+        cannot be back-propagated.
+
+        Extension (keyword-only): ``noise=(pos_noise (N,3), u (N,C))`` feeds the normal draw of :461 and the uniforms of
+        log_sample_categorical (:98-104, inside q_v_sample :366-374) instead of torch's generator (parity tests)."""
+        if torch.is_grad_enabled():
+            raise NotImplementedError("shapemol_amd evaluates the diffusion loss without gradients (validation); wrap the call "
+                                      "in torch.no_grad() -- the training step (backward) is not part of the accelerated path")
+        if self.v_mode != "uniform":
+            raise NotImplementedError("v_mode = 'uniform' only (the shipped training configuration)")
+        pos = _check_device_tensor("ligand_pos", ligand_pos, torch.float32)
+        v = _check_device_tensor("ligand_v", ligand_v, torch.int64)
+        batch = _check_device_tensor("batch_ligand", batch_ligand, torch.int64)
+        shape = _check_device_tensor("ligand_shape", ligand_shape, torch.float32)
+        if self.center_pos_mode == "center":
+            n_all = int(shape.view(-1, self.dims.S, 3).shape[0])
+            pos = pos - self._scatter_mean(pos, batch, n_all)[batch]
+        elif self.center_pos_mode not in (None, "none"):
+            raise NotImplementedError(self.center_pos_mode)
+        shape = shape.view(-1, self.dims.S, 3)
+        num_graphs = shape.shape[0]
+        if time_step is None:
+            time_step, _ = self.sample_time(num_graphs, pos.device)
+        t = _check_device_tensor("time_step", time_step, torch.int64)
+        # perturb positions and atom types
+        a_pos = self._table("alphas_cumprod")[t][batch].unsqueeze(-1)
+        pos_noise = _check_device_tensor("noise[0]", noise[0], torch.float32) if noise is not None else torch.zeros_like(pos).normal_()
+        pos_pert = a_pos.sqrt() * pos + (1.0 - a_pos).sqrt() * pos_noise
+        log_v0 = torch.log(torch.nn.functional.one_hot(v, self.num_classes).float().clamp(min=1e-30))
+        tb = t[batch]
+        log_qvt = self._v_mix(log_v0, self._table("log_alphas_cumprod_v")[tb].unsqueeze(-1), self._table("log_one_minus_alphas_cumprod_v")[tb].unsqueeze(-1))
+        v_pert = log_sample_categorical(log_qvt, u=(noise[1] if noise is not None else None))
+        log_vt = torch.log(torch.nn.functional.one_hot(v_pert, self.num_classes).float().clamp(min=1e-30))
+        if not eval_mode:       # classifier-free condition masking (:480-484; cond_mask_prob = 0 in the shipped configuration)
+            keep = torch.bernoulli(torch.ones(num_graphs) * (1 - (self.cond_mask_prob or 0.0))).to(shape.device)
+            shape = keep.view(-1, 1, 1) * shape
+        preds = self(pos_pert, v_pert, batch, shape, time_step=t)
+        pred_pos, pred_v = preds["pred_ligand_pos"], preds["pred_ligand_v"]
+        # atom types: KL between the true and the model posterior, decoder NLL at t = 0
+        log_recon = torch.nn.functional.log_softmax(pred_v, dim=-1)
+        log_model = self._q_v_posterior(log_recon, log_vt, t, batch)
+        log_true = self._q_v_posterior(log_v0, log_vt, t, batch)
+        kl = (log_true.exp() * (log_true - log_model)).sum(dim=1)
+        nll = -(log_v0.exp() * log_model).sum(dim=1)
+        mask = (t == 0).float()[batch]
+        kl_v = self._scatter_mean(mask * nll + (1.0 - mask) * kl, batch, num_graphs)
+        loss_pos = self._scatter_mean(((pred_pos - pos) ** 2).sum(-1), batch, num_graphs)
+        if self.loss_weight_type == "noise_level":
+            loss_pos = torch.mean(self._table("loss_pos_step_weight")[t] * loss_pos)
+        else:
+            loss_pos = torch.mean(loss_pos)
+        loss_v = torch.mean(kl_v)
+        return {"loss_pos": loss_pos, "loss_v": loss_v, "loss": loss_pos + loss_v * self.loss_v_weight, "x0": pos,
+                "ligand_pos_perturbed": pos_pert, "ligand_v_perturbed": v_pert, "pred_ligand_pos": pred_pos,
+                "pred_ligand_v": pred_v, "ligand_v_recon": torch.nn.functional.softmax(pred_v, dim=-1)}
 
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()
@@ -223,6 +334,7 @@ class ScorePosNet3D(nn.Module):
         shape = _check_device_tensor("ligand_shape", ligand_shape, torch.float32).view(-1, self.dims.S, 3)
         n, b, cc, dev = pos.shape[0], shape.shape[0], self.dims.C, pos.device
         ctx = self._context(dev)
+        self._sync_bn_mode(ctx)
         lib = _lib.load()
         eps = u = None
         if noise is not None:

@@ -142,6 +142,17 @@ def synthetic_state_dict(model_cfg, seed=7, num_classes=15):
     return {k: out[k] for k in spec}
 
 
+def running_stats(num_layers, heads, seed=23):
+    """Non-trivial batch-norm running statistics {key: ndarray} for the evaluation-mode tests (synthetic_state_dict leaves
+    them at 0 / 1, a fresh module's values): means around the typical vector norms, variances in [0.05, 0.55]."""
+    out = {}
+    for l in range(num_layers):
+        p = f"refine_net.base_block.{l}.h2x_layers.0.shape_linear.batchnorm.bn."
+        out[p + "running_mean"] = (0.4 + 1.2 * hash_uniform((heads,), key_tag(p + "running_mean"), seed)).astype(np.float32)
+        out[p + "running_var"] = (0.05 + 0.5 * hash_uniform((heads,), key_tag(p + "running_var"), seed)).astype(np.float32)
+    return out
+
+
 def shape_encoder_state_dict(hidden=128, latent=32, layers=4, seed=17):
     """Hash-filled weights of the shape encoder under the keys of shapemol_amd.shape_encoder.VN_DGCNN_Encoder
     (conv_pos.*, blocks.{i}.*, conv_c.*; batch-norm running statistics are not part of the forward)."""

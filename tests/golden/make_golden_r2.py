@@ -10,6 +10,7 @@ because these take tens of CPU-minutes while make_golden.py's set regenerates in
     python tests/golden/make_golden_r2.py k32       # configs[4]: <=80 atoms, k=32, L=8, B=64
     python tests/golden/make_golden_r2.py guide     # point-cloud shape guidance: the function alone and inside a chain
     python tests/golden/make_golden_r2.py se        # frozen shape encoder (VN_DGCNN_Encoder), 3 clouds of 512 points
+    python tests/golden/make_golden_r2.py loss      # get_diffusion_loss as validate() calls it, module in eval and in train mode
     python tests/golden/make_golden_r2.py all
 
 Noise is the hash noise of synth.step_noise (a pure function of (seed, step)), so the fixtures
@@ -155,11 +156,57 @@ def shape_encoder_fixture():
     print("shape_encoder:", tuple(z.shape), "max |z|", float(z.abs().max()), flush=True)
 
 
+@contextlib.contextmanager
+def fed_normal(draws):
+    """Replace Tensor.normal_() (the in-place draw of get_diffusion_loss, molopt_score_model.py:461) by given values."""
+    real = torch.Tensor.normal_
+    it = iter(draws)
+    def normal_(t, *a, **k):
+        t.copy_(torch.from_numpy(next(it)).to(t.dtype))
+        return t
+    torch.Tensor.normal_ = normal_
+    try:
+        yield
+    finally:
+        torch.Tensor.normal_ = real
+
+
+def loss_fixture():
+    """get_diffusion_loss(eval_mode=True, time_step=...) as validate() calls it (scripts/train_diffusion.py:168-192): once
+    with the module in eval mode (running batch-norm statistics, set to non-trivial values) and once in train mode."""
+    model, _ = G.load_reference_model()
+    G.synthetic_load(model, seed=7)
+    rs = synth.running_stats(len(model.refine_net.base_block), 16, seed=23)
+    sd = model.state_dict()
+    for k, v in rs.items():
+        assert k in sd, k
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd, strict=True)
+    B, seed = 12, 41
+    bb = synth.synthetic_batch(B, seed=seed)
+    n = len(bb["batch"])
+    tt = (synth.hash_u24(B, 88, 3) % 1000).astype(np.int64)
+    tt[0], tt[1], tt[2] = 0, 0, 999              # the decoder-NLL branch (t = 0) and the last step
+    pos0 = (synth.hash_normal((n, 3), 501, seed) * 1.5).astype(np.float32)     # "clean" molecules
+    noise = synth.hash_normal((n, 3), 502, seed)
+    u = synth.hash_uniform((n, 15), 503, seed)
+    rec = {}
+    for mode in ("eval", "train"):
+        model.eval() if mode == "eval" else model.train()
+        with torch.no_grad(), fed_normal([noise]), G.fed_noise(None, [u]), contextlib.redirect_stdout(open(os.devnull, "w")):
+            r = model.get_diffusion_loss(t_(pos0), t_(bb["init_v"]), t_(bb["batch"]), t_(bb["shape"]).view(B, -1), time_step=t_(tt), eval_mode=True)
+        for k in ("loss_pos", "loss_v", "loss", "ligand_pos_perturbed", "ligand_v_perturbed", "pred_ligand_pos", "pred_ligand_v", "ligand_v_recon"):
+            rec[f"{mode}_{k}"] = r[k].numpy()
+        print(f"loss[{mode}]: loss {float(r['loss']):.6f}  pos {float(r['loss_pos']):.6f}  v {float(r['loss_v']):.6f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "diffusion_loss_b12.npz"), B=B, seed=seed, t=tt, counts=bb["counts"], pos=pos0,
+                        running_stats_seed=23, **rec)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     # float32 reductions of the CPU BLAS depend on the thread count: every fixture records the count it was made with
     # (the 47-minute B=256 chain ran on 6 threads beside a build, the k=32 set on 3), and a regeneration uses the same
-    threads = {"b256": 6, "b1024": 8, "k32": 3, "guide": 8, "se": 8}
+    threads = {"b256": 6, "b1024": 8, "k32": 3, "guide": 8, "se": 8, "loss": 8}
     def use_threads(task):
         torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", threads[task])))
     torch.set_num_threads(8)
@@ -172,6 +219,9 @@ def main():
         if what in ("b256", "all"):
             use_threads("b256")
             chain(model, "b256_s1000", 256, 1000, 13, every=50, head=4, max_atoms=38)
+    if what in ("loss", "all"):
+        use_threads("loss")
+        loss_fixture()
     if what in ("se", "all"):
         use_threads("se")
         G.install_stand_ins()

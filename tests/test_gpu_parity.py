@@ -765,3 +765,41 @@ def test_folded_coordinate_update_equals_separate_launch():
     r.load_batch(big["init_pos"], big["init_v"], big["batch"], big["shape"])      # restores the true hint: too large to fold -> plain path
     r.run(3)
     r.synchronize()
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_diffusion_loss_golden(mode):
+    """get_diffusion_loss as validate() calls it (scripts/train_diffusion.py:168-192: given time steps, eval_mode=True, no
+    gradients) against the reference's own run: perturbed inputs, network outputs and the three loss values; module in eval
+    mode (batch-norm on its running statistics, set to non-trivial values) and in train mode (the batch's)."""
+    import shapemol_amd
+    from util import model_cfg, record
+    f = golden("diffusion_loss_b12.npz")
+    cfg = model_cfg()
+    m = shapemol_amd.ScorePosNet3D(cfg, 15)
+    sdn = synth.synthetic_state_dict(cfg, seed=7)
+    sdn.update(synth.running_stats(m.dims.L, m.dims.heads, int(f["running_stats_seed"])))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+    m = m.to(DEV)
+    m.eval() if mode == "eval" else m.train()
+    B, seed = int(f["B"]), int(f["seed"])
+    bb = synth.synthetic_batch(B, seed=seed)
+    n = len(bb["batch"])
+    noise, u = synth.hash_normal((n, 3), 502, seed), synth.hash_uniform((n, 15), 503, seed)
+    args = (T(f["pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV).view(B, -1))
+    with pytest.raises(NotImplementedError, match="without gradients"):
+        m.get_diffusion_loss(*args, time_step=T(f["t"], DEV), eval_mode=True)
+    with torch.no_grad():
+        r = m.get_diffusion_loss(*args, time_step=T(f["t"], DEV), eval_mode=True, noise=(T(noise, DEV), T(u, DEV)))
+    m.check_status()
+    assert np.array_equal(r["ligand_v_perturbed"].cpu().numpy(), f[f"{mode}_ligand_v_perturbed"])
+    assert maxabs(r["ligand_pos_perturbed"], f[f"{mode}_ligand_pos_perturbed"]) < 1e-6
+    errs = {k: maxabs(r[k], f[f"{mode}_{k}"]) for k in ("pred_ligand_pos", "pred_ligand_v", "ligand_v_recon")}
+    rel = {k: abs(float(r[k]) - float(f[f"{mode}_{k}"])) / max(1.0, abs(float(f[f"{mode}_{k}"]))) for k in ("loss_pos", "loss_v", "loss")}
+    record("diffusion_loss_golden", mode=mode, **errs, **{f"rel_{k}": v for k, v in rel.items()})
+    assert max(errs.values()) < FWD_TOL, errs
+    assert max(rel.values()) < 2e-5, rel
+    # the two modes must differ (the running statistics are really used)
+    other = "train" if mode == "eval" else "eval"
+    assert abs(float(r["loss_pos"]) - float(f[f"{other}_loss_pos"])) > 0.1
+

@@ -111,3 +111,29 @@ def test_shape_encoder_oracle_golden():
     z = SE.encode(sd, torch.from_numpy(f["points"]), int(f["layers"]), int(f["k"]))
     assert maxabs(z, f["latent"]) < 2e-5
 
+
+def _loss_inputs(f):
+    B, seed = int(f["B"]), int(f["seed"])
+    bb = synth.synthetic_batch(B, seed=seed)
+    n = len(bb["batch"])
+    return bb, synth.hash_normal((n, 3), 502, seed), synth.hash_uniform((n, 15), 503, seed)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_diffusion_loss_oracle_golden(mode):
+    """oracle.diffusion_loss against the reference's get_diffusion_loss(eval_mode=True, time_step=...) (the call of
+    validate(), scripts/train_diffusion.py:168-192), module in eval mode (running batch-norm statistics) and in train mode."""
+    f = golden("diffusion_loss_b12.npz")
+    sd, dm, cfg, sdn = oracle_model()
+    sd = dict(sd)
+    sd.update({k: torch.from_numpy(v) for k, v in synth.running_stats(dm.L, dm.heads, int(f["running_stats_seed"])).items()})
+    bb, noise, u = _loss_inputs(f)
+    r = O.diffusion_loss(sd, dm, T(f["pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(f["t"]), T(noise), T(u),
+                         bn_eval=(mode == "eval"), loss_v_weight=cfg["loss_v_weight"], loss_weight_type=cfg["loss_weight_type"])
+    assert np.array_equal(r["ligand_v_perturbed"].numpy(), f[f"{mode}_ligand_v_perturbed"])
+    assert maxabs(r["ligand_pos_perturbed"], f[f"{mode}_ligand_pos_perturbed"]) < 1e-6
+    for k in ("pred_ligand_pos", "pred_ligand_v", "ligand_v_recon"):
+        assert maxabs(r[k], f[f"{mode}_{k}"]) < FWD_TOL, k
+    for k in ("loss_pos", "loss_v", "loss"):
+        assert abs(float(r[k]) - float(f[f"{mode}_{k}"])) < 1e-5 * max(1.0, abs(float(f[f"{mode}_{k}"]))), k
+
