@@ -21,7 +21,7 @@ def run_forward(m, f, tkey, pos="pos", v="v"):
 
 def test_library_loaded_and_device():
     from shapemol_amd import _lib
-    assert _lib.load().shapemol_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.load().shapemol_abi_version() == _lib.ABI_VERSION == 3
     assert torch.cuda.is_available()
 
 
