@@ -496,7 +496,10 @@ struct shapemol_ctx {
     hipGraphExec_t gexec = nullptr, gexec_u = nullptr;     // one step / kGraphUnroll steps
     int64_t n_captures = 0;                                // graph captures so far (debug_read "captures")
     // the captured step depends on the batch geometry only: seed, noise and trajectory pointers live in chain_params
-    struct GraphKey { int64_t N = 0, B = 0; int guided = 0, fold = 0; bool operator==(const GraphKey &o) const { return N == o.N && B == o.B && guided == o.guided && fold == o.fold; } } gkey{};
+    // what a captured step depends on besides the options (which drop the graphs when set): sizes, guidance, and the two
+    // launch decisions taken from the max_mol_atoms hint (folded coordinate update, fused graph kernel)
+    struct GraphKey { int64_t N = 0, B = 0; int guided = 0, fold = 0, gfuse = 0;
+                      bool operator==(const GraphKey &o) const { return N == o.N && B == o.B && guided == o.guided && fold == o.fold && gfuse == o.gfuse; } } gkey{};
     void drop_graphs() {      // a replay may still be in flight: drain the device before destroying the executables
         if (!gexec && !gexec_u) return;
         hipDeviceSynchronize();
@@ -1183,6 +1186,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
     if (use_graph && !c->prof_on) {
         shapemol_ctx::GraphKey key{};
         key.N = N; key.B = B; key.guided = c->g_points > 0; key.fold = vn_fold_ok(c, (int)N);
+        key.gfuse = c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap;
         // two executables: one reverse step, and kGraphUnroll steps back to back (the gap between two graph launches,
         // ~5 us, is then paid once per kGraphUnroll steps); every step reads its index from the device-side counter
         auto capture = [&](int n_steps, hipGraphExec_t *exec) -> int {
