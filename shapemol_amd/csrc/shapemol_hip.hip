@@ -799,7 +799,8 @@ int run_prep(shapemol_ctx *c, hipStream_t s, const int64_t *d_batch, int64_t N, 
                     c->P(c->dm.inv.w2), c->P(c->dm.inv.b2), c->inv, S, SL};
     LAUNCH("prep", SMK(shape_invariant_kernel, dim3(B), dim3(64), 0, s, si));
     // every step-invariant shape term (layer-0 x2h; per layer h2x | next x2h) and the shape part of every VN-linear: two launches
-    LAUNCH("prep", SMK(shape_term_multi_kernel, dim3((unsigned)B, (unsigned)c->n_prep_terms), dim3(256), 0, s, c->prep_terms));
+    if (SL == 32) LAUNCH("prep", SMK(shape_term_multi_tiled_kernel<32>, dim3((unsigned)((B + kShapeTermMols - 1) / kShapeTermMols), (unsigned)c->n_prep_terms), dim3(256), 0, s, c->prep_terms, (int)B));
+    else LAUNCH("prep", SMK(shape_term_multi_kernel, dim3((unsigned)B, (unsigned)c->n_prep_terms), dim3(256), 0, s, c->prep_terms));
     LAUNCH("prep", SMK(vn_shape_multi_kernel, dim3((unsigned)B, (unsigned)L), dim3(128), 0, s, d_shape, c->prep_vn));
     (void)SL; (void)S; (void)hd;
     return 0;
@@ -833,7 +834,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     } else {
         LAUNCH("embed", SMK(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
     }
-    const bool graph_fused = c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap && KP <= 32;
+    // (chains only: the hint is set for the batch of a chain; a score evaluation on other data must not trust a stale one)
+    const bool graph_fused = sampling && c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap && KP <= 32;
     if (graph_fused) {
         GraphArgs ga{x_in, c->mol_span, n, g.knn, KP, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
                      c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, c->status + ST_SPAN};
@@ -1340,7 +1342,7 @@ int shapemol_status(shapemol_ctx *c, int32_t *flags_out) {
     if (f[ST_BATCH]) return fail("batch vector is not sorted ascending or names a molecule >= n_mols; results are invalid");
     if (f[ST_ATOM_TYPE]) return fail("an atom type is outside [0, num_classes); results are invalid");
     if (f[ST_TIME]) return fail("a time step is outside [0, num_timesteps); results are invalid");
-    if (f[ST_SPAN]) return fail("a molecule is larger than the max_mol_atoms hint allows for the folded coordinate update; results are invalid");
+    if (f[ST_SPAN]) return fail("a molecule is larger than the max_mol_atoms hint says (folded coordinate update / fused graph kernel); results are invalid");
     if (f[ST_RANGE]) return fail("an activation left the fp16 range of the two-piece f16 node kernels (|x| >= 6e4 or NaN); results are invalid: set option node_f16 = 0 (exactly split bf16 kernels)");
     if (f[ST_VN_BARRIER]) return fail("grid barrier of the fused coordinate update timed out (workgroups not co-resident); results are invalid");
     return 0;

@@ -132,6 +132,38 @@ __global__ void shape_term_multi_kernel(const ShapeTermArgs *terms) {
     }
 }
 
+// The same with the molecule loop inside: a thread keeps its weight row (SL floats) in registers and applies it to the
+// kShapeTermMols molecules of its workgroup, whose invariant embeddings sit in LDS (the kernel above re-reads the row, 32
+// dependent strided loads, for every molecule: 134 us for 23 terms x 256 molecules against ~10 us here; once per chain).
+// Same sums in the same order (bias first, then the SL products ascending).
+constexpr int kShapeTermMols = 32;
+template <int SL>
+__global__ void __launch_bounds__(256) shape_term_multi_tiled_kernel(const ShapeTermArgs *terms, int n_mols) {
+    const ShapeTermArgs a = terms[blockIdx.y];
+    __shared__ float invs[kShapeTermMols][SL];
+    const int b0 = blockIdx.x * kShapeTermMols, nb = min(kShapeTermMols, n_mols - b0);
+    for (int idx = threadIdx.x; idx < nb * SL; idx += blockDim.x) invs[idx / SL][idx % SL] = a.inv[(size_t)b0 * SL + idx];
+    __syncthreads();
+    for (int f = threadIdx.x; f < 4 * a.H; f += blockDim.x) {
+        const int blk = f / a.H, ff = f % a.H;
+        if (blk & 1) {
+            for (int b = 0; b < nb; ++b) a.add[(size_t)(b0 + b) * a.ld + f] = 0.f;
+            continue;
+        }
+        const float *w = (blk == 0 ? a.wk : a.wv) + (size_t)ff * a.ldw;
+        const float bias = (blk == 0 ? a.bk : a.bv)[ff];
+        float wr[SL];
+#pragma unroll
+        for (int i = 0; i < SL; ++i) wr[i] = w[i];
+        for (int b = 0; b < nb; ++b) {
+            float v = bias;
+#pragma unroll
+            for (int i = 0; i < SL; ++i) v += wr[i] * invs[b][i];
+            a.add[(size_t)(b0 + b) * a.ld + f] = v;
+        }
+    }
+}
+
 // Shape part of the VN-linear inputs (step-invariant): ps[b][which][c][dim] =
 //   sum_s W_which[c][1 + heads + s] * shape[b][s][dim]      (tmp_output concat, uni_transformer.py:154)
 struct VnShapeArgs {
