@@ -318,7 +318,7 @@ def diffusion_loss(sd, dm, pos, v, batch, shape, t, pos_noise, u, bn_eval=True, 
 
 
 @torch.no_grad()
-def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, keep_traj=True, guidance=None):
+def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, keep_traj=True, guidance=None, bn_eval=False):
     """Reverse chain t = T-1 ... T-num_steps with host-fed noise ``noise_fn(step) -> (eps, u)``
     (numpy or torch arrays; per step eps (N,3) first, then u (N,C), the reference's draw order).
     guidance = (cloud, radius, grad_step, draws (S,5,N)): point-cloud guidance of the predicted x0 while t > grad_step
@@ -329,7 +329,7 @@ def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, ke
     out = {k: [] for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj", "pos_cond_traj", "v_cond_traj")}
     for s, i in enumerate(reversed(range(dm.T - num_steps, dm.T))):
         t = torch.full((B,), i, dtype=torch.long)
-        pr = score(sd, dm, pos, v, batch, shape, t)
+        pr = score(sd, dm, pos, v, batch, shape, t, bn_eval=bn_eval)      # bn_eval: a module put in eval mode before sampling
         if guidance is not None and i > guidance[2]:
             pr["pred_ligand_pos"] = torch.from_numpy(pointcloud_shape_guidance(guidance[0], guidance[1], pr["pred_ligand_pos"].numpy(),
                                                                               guidance[3][s]))

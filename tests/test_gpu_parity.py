@@ -803,3 +803,36 @@ def test_diffusion_loss_golden(mode):
     other = "train" if mode == "eval" else "eval"
     assert abs(float(r["loss_pos"]) - float(f[f"{other}_loss_pos"])) > 0.1
 
+
+def test_chain_in_eval_mode_matches_oracle():
+    """A module put in eval mode before sampling normalises the coordinate updates with the running statistics in every
+    path that consumes them (the update folded into the x2h kernels and into the DDPM kernel, and the separate vn_apply
+    launches): a short chain against the oracle (whose eval-mode evaluation is pinned by diffusion_loss_b12.npz)."""
+    import shapemol_amd
+    from util import model_cfg, record
+    cfg = model_cfg()
+    m = shapemol_amd.ScorePosNet3D(cfg, 15)
+    sdn = synth.synthetic_state_dict(cfg, seed=7)
+    sdn.update(synth.running_stats(m.dims.L, m.dims.heads, 23))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+    m = m.to(DEV).eval()
+    sd, dm = O.state_dict_from_numpy(sdn), O.Dims(cfg)
+    bb = synth.synthetic_batch(6, seed=17)
+    S = 8
+    eps, u = hash_noise(len(bb["batch"]), S, 17)
+    ref = O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S,
+                         lambda s: (eps[s], u[s]), bn_eval=True)
+    errs = {}
+    for fold in (1, 0):
+        m.set_option("vn_fold", fold)
+        r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
+        assert torch.equal(r["v"].cpu(), ref["v"]), fold
+        errs[f"pos_fold{fold}"] = maxabs(r["pos"], ref["pos"])
+        errs[f"pos_cond_fold{fold}"] = maxabs(torch.stack(r["pos_cond_traj"]), torch.stack(ref["pos_cond_traj"]))
+    record("chain_eval_mode_vs_oracle", **errs)
+    assert max(errs.values()) < POS_TOL, errs
+    # and it differs from the train-mode chain (the statistics are really used)
+    m.train()
+    r_train = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
+    assert maxabs(r_train["pos"], ref["pos"]) > 1e-3
+
