@@ -695,7 +695,7 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
             const int per = grid * waves;
             for (int base = 0; base < njobs; base += per) {
                 Edge16Args b = a;
-                b.job_base = base; b.job_end = std::min(njobs, base + per);
+                b.job_base = base; b.job_end = std::min(njobs, base + per); b.nwave = waves;
                 const int g2 = std::max(1, std::min(grid, (b.job_end - base + waves - 1) / waves));
                 if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(g2), dim3(waves * 64), shm, s, b));
                 else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(g2), dim3(waves * 64), shm, s, b));
@@ -703,8 +703,10 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
             return 0;
         }
         if (c->edge_tiles == 1) {
-            if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
-            else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, a));
+            Edge16Args b = a;
+            b.nwave = waves;
+            if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, b));
+            else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, b));
             return 0;
         }
     }
@@ -714,9 +716,11 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
     const int waves = c->edge_threads > 0 ? std::min(8, c->edge_threads / 64) : 8;      // option edge_waves (sweeps); 8 = two per SIMD
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
     const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float) + (H2X ? 512 * 16 : 0);
-    if (KP == 8) LAUNCH(nm, SMK((edge16x2_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
-    else if (KP == 16) LAUNCH(nm, SMK((edge16x2_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
-    else LAUNCH(nm, SMK((edge16x2_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    Edge16Args b2 = a;
+    b2.nwave = waves;
+    if (KP == 8) LAUNCH(nm, SMK((edge16x2_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, b2));
+    else if (KP == 16) LAUNCH(nm, SMK((edge16x2_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, b2));
+    else LAUNCH(nm, SMK((edge16x2_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, b2));
     return 0;
 }
 
@@ -740,7 +744,7 @@ int launch_x2h_chain(shapemol_ctx *c, hipStream_t s, const Edge16Args &a, const 
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
     const size_t shm = 2 * EdgeImage16<H, H / 16>::TOTAL * sizeof(float) + (a.vf.enable ? kVnFoldBytes : 0);
     Edge16Args b = a;
-    b.job_base = 0; b.job_end = njobs;
+    b.job_base = 0; b.job_end = njobs; b.nwave = waves;
     if (KP == 8) LAUNCH("edge_x2h_chain", SMK((x2h_chain16_kernel<H, 8>), dim3(grid), dim3(waves * 64), shm, s, b, na, c->status + ST_RANGE));
     else LAUNCH("edge_x2h_chain", SMK((x2h_chain16_kernel<H, 16>), dim3(grid), dim3(waves * 64), shm, s, b, na, c->status + ST_RANGE));
     return 0;
@@ -767,7 +771,7 @@ int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float 
     const int tpg = std::max(1, (n_ct + want_groups - 1) / want_groups);
     const int agroups = (n_ct + tpg - 1) / tpg;
     const bool f16 = c->lin_bf16 && c->node_f16;
-    NodeLinArgs a{in, f16 ? wimg16 : (c->lin_bf16 ? wimg6 : wimg), add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps};
+    NodeLinArgs a{in, f16 ? wimg16 : (c->lin_bf16 ? wimg6 : wimg), add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps, nwave};
     if (f16) {
         const size_t shm = (size_t)std::min(tpg, kLin16Chunk) * 2 * H * 32;
         LAUNCH(name, SMK(node_linear16_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a, c->status + ST_RANGE));

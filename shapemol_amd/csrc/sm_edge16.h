@@ -134,6 +134,8 @@ struct Edge16Args {
     float *out;             // x2h: [N][H]; h2x: [N][16][3]
     int n_atoms, ld_pre;
     int job_base, job_end;            // edge16_kernel: this launch covers jobs [job_base, job_end) (job_end = 0: all of them)
+    int nwave;                        // waves per workgroup (= blockDim.x / 64; as an argument because reading blockDim costs
+                                      // two dependent loads from the implicit kernel arguments at the head of every launch)
     unsigned long long *stamps;       // diagnostic build only
     EdgeFusedArgs::VnFuse vn;         // h2x: VN-linear + batch statistics behind the attention (enable = 0 or 2)
     float *xsum;                      // h2x with vn.enable: [N][3] sum of the attention rows per atom (for a following VnFold), or nullptr
@@ -157,7 +159,7 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
     constexpr int HD = H / 8;                                     // heads = VN channels
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = a.nwave;
     const int n = lane & 15, g = lane >> 4;
     float cen[5];
     rbf_centres(g, cen);
@@ -279,7 +281,7 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
                 rstd = 1.0f / sqrtf((float)var + 1e-5f);
                 bng = a.vf.bn_g[c]; bnb = a.vf.bn_b[c];
             }
-            for (int it = threadIdx.x; it < span_n * 16; it += blockDim.x) {       // item = (atom of the span, channel)
+            for (int it = threadIdx.x; it < span_n * 16; it += nwave * 64) {       // item = (atom of the span, channel)
                 const int va = span0 + (it >> 4);
                 float o[3] = {0.f, 0.f, 0.f};
                 if (c < HD) {
@@ -557,7 +559,7 @@ edge16x2_kernel(Edge16Args a) {
     constexpr int HD = H / 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = a.nwave;
     const int n = lane & 15, g = lane >> 4;
     float cen[5];
     rbf_centres(g, cen);

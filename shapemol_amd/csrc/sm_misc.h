@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(256) ddpm_step16_kernel(DdpmArgs aa) {
     struct : DdpmArgs, ChainParams {} a;
     static_cast<DdpmArgs &>(a) = aa;
     static_cast<ChainParams &>(a) = *aa.cp;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = blockIdx.x * 256 + threadIdx.x;               // (launched with 256 threads: no blockDim read)
     const int i_raw = gid >> 4, c = gid & 15;
     const int step = a.step_cur ? *a.step_cur : 0;
     const bool atom_ok = i_raw < a.n_atoms;

@@ -38,6 +38,7 @@ struct NodeLinArgs {
     int n_atoms, n_out_tiles, tiles_per_group;
     int ld_add, ld_out;           // row strides of add_mol and out (floats)
     unsigned long long *stamps;   // diagnostic build only
+    int nwave;                    // waves per workgroup (node_linear16_kernel reads it here instead of blockDim)
 };
 
 constexpr int kLinChunk = 8;      // column tiles staged in LDS at a time (shared by the workgroup's waves)

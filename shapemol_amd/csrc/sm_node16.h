@@ -33,7 +33,7 @@ node_linear16_kernel(NodeLinArgs a, int *range_flag) {
     u32x4 *frag = reinterpret_cast<u32x4 *>(lin16_lds);             // [tile][piece][NB][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int nwave = blockDim.x >> 6;
+    const int nwave = a.nwave;
     const int ogroups = (a.n_out_tiles + nwave - 1) / nwave;
     const int ot_raw = (blockIdx.x % ogroups) * nwave + wave;
     const bool ot_ok = ot_raw < a.n_out_tiles;
@@ -53,7 +53,7 @@ node_linear16_kernel(NodeLinArgs a, int *range_flag) {
     for (int cb = ct0; cb < ct1; cb += kLin16Chunk) {
         const int nc = min(kLin16Chunk, ct1 - cb);
         __syncthreads();                                            // previous chunk fully consumed
-        for (int idx = threadIdx.x; idx < nc * NB * 64; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < nc * NB * 64; idx += nwave * 64) {
             const int sl = idx & 63, sb = (idx >> 6) % NB, sc = idx / (64 * NB);
             const int at = min((cb + sc) * 16 + (sl & 15), a.n_atoms - 1);
             const float *src = a.in + (size_t)at * H + 32 * sb + 4 * (sl >> 4);
@@ -177,7 +177,7 @@ struct Node16 {
 //                  BEFORE that barrier (a wave that has finished its edge job has its registers free while the slower
 //                  waves finish theirs).  Waves >= NT help with the staging and retire.
 template <int H, bool FUSED, int SEGW>
-SM_DEV void chain16_body(const NodeChainArgs &a, int *range_flag, int first_atom, int ncols, const float4 (&keep)[H / 16]) {
+SM_DEV void chain16_body(const NodeChainArgs &a, int *range_flag, int first_atom, int ncols, const float4 (&keep)[H / 16], int nthreads) {
     using L = Chain16Lds<H>;
     using N16 = Node16<H>;
     constexpr int NT = H / 16, NB = H / 32, CC = CHAIN_COLS;
@@ -253,7 +253,7 @@ SM_DEV void chain16_body(const NodeChainArgs &a, int *range_flag, int first_atom
             }
         }
         // columns beyond the workgroup's atoms: zero attention fragments
-        for (int idx = threadIdx.x; idx < CC * NB * 64; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < CC * NB * 64; idx += nthreads) {
             const int sl = idx & 63, sb = (idx >> 6) % NB, sc = idx / (64 * NB);
             if (sc * 16 + (sl & 15) >= ncols) {
                 u32x4 *dst = fin + (sb * CC + sc) * 64 + frag_slot(sb, sl);
@@ -394,7 +394,7 @@ template <int H>
 __global__ void __launch_bounds__(H * 4)
 node_chain16_kernel(NodeChainArgs a, int *range_flag) {
     float4 keep[H / 16];
-    chain16_body<H, false, 8>(a, range_flag, blockIdx.x * CHAIN_COLS * 16, CHAIN_COLS * 16, keep);
+    chain16_body<H, false, 8>(a, range_flag, blockIdx.x * CHAIN_COLS * 16, CHAIN_COLS * 16, keep, H * 4);
 }
 
 // x2h attention and the node stage of the same layer in one launch (one job per wave, >= H / 16 waves per workgroup): the
@@ -405,9 +405,9 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
 x2h_chain16_kernel(Edge16Args e, NodeChainArgs a, int *range_flag) {
     float4 keep[H / 16];
     edge16_body<H, KP, false, true, true>(e, keep);
-    const int nwave = blockDim.x >> 6, apj = 16 / KP;
+    const int nwave = e.nwave, apj = 16 / KP;
     const int first_atom = (e.job_base + blockIdx.x * nwave) * apj;
-    chain16_body<H, true, KP>(a, range_flag, first_atom, nwave * apj, keep);
+    chain16_body<H, true, KP>(a, range_flag, first_atom, nwave * apj, keep, nwave * 64);
 }
 
 template <int H>
@@ -430,9 +430,9 @@ node_prologue16_kernel(NodePrologueArgs a, int *range_flag) {
     // ---- bookkeeping of the evaluation ------------------------------------------------------------------
     const int step = a.step_ptr ? *a.step_ptr : 0;
     {
-        const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+        const int gid = blockIdx.x * (H * 4) + threadIdx.x;           // (the launch uses H * 4 threads: no blockDim read)
         if (gid == 0 && a.step_ptr) *a.step_cur = step;
-        for (int i = gid; i < a.bn_acc_len; i += gridDim.x * blockDim.x) a.bn_acc[i] = 0.0;
+        for (int i = gid; i < a.bn_acc_len; i += gridDim.x * (H * 4)) a.bn_acc[i] = 0.0;
     }
     // ---- stage 0: embedding of the workgroup's atoms -> global h0 and LDS fragments ----------------------
     u32x4 wq1[2][NB], wl[2][NB];
