@@ -842,7 +842,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     const bool graph_fused = sampling && c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap && KP <= 32;
     if (graph_fused) {
         GraphArgs ga{x_in, c->mol_span, n, g.knn, KP, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
-                     c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, c->status + ST_SPAN};
+                     c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, c->status + ST_SPAN, c->kstamp_sel == 4 ? c->kstamps : nullptr};
         const int apb = kGraphWaves * (KP >= 16 ? 1 : 16 / KP);      // atoms per workgroup
         if (KP == 8) LAUNCH("graph", SMK((graph_kernel<H, 8>), dim3((n + apb - 1) / apb), dim3(kGraphWaves * 64), 0, s, ga));
         else if (KP == 16) LAUNCH("graph", SMK((graph_kernel<H, 16>), dim3((n + apb - 1) / apb), dim3(kGraphWaves * 64), 0, s, ga));

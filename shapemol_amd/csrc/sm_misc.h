@@ -503,6 +503,7 @@ struct GraphArgs {
     const float *w1, *b1, *g, *be, *w2, *b2;   // edge-weight MLP (as EdgeWeightArgs)
     float *ew;              // [N][KP]
     int *span_flag;         // status flag raised if a molecule exceeds kGraphCap atoms (the max_mol_atoms hint was wrong)
+    unsigned long long *stamps;   // diagnostic build only
 };
 template <int H, int KP>
 __global__ void __launch_bounds__(kGraphWaves * 64)
@@ -513,7 +514,7 @@ graph_kernel(GraphArgs a) {
     constexpr int NQ = kGraphCap / LPA;                   // candidate chunks per lane
     constexpr int TPW = KP > 16 ? KP / 16 : 1;            // tiles per wave
     __shared__ float w1s[H * 20];
-    __shared__ float dist[kGraphWaves][APW][kGraphCap];
+    __shared__ unsigned long long dkey[kGraphWaves][APW][kGraphCap];   // (distance bits, index) of the molecule's atoms
     __shared__ float xs[kGraphWaves][APW][kGraphCap][3];  // the molecule's coordinates (the weight stage's neighbours live there)
     __shared__ int row[kGraphWaves][APW * KP];
     __shared__ __attribute__((aligned(16))) float prm[4][H];        // b1 | gamma | beta | w2
@@ -523,6 +524,7 @@ graph_kernel(GraphArgs a) {
     const int i_raw = (blockIdx.x * kGraphWaves + wave) * APW + sub;
     const bool valid = i_raw < a.n_atoms;
     const int i = valid ? i_raw : a.n_atoms - 1;
+    SM_TICK(a.stamps, 0);
     const int2 span = a.mol_span[i];
     for (int idx = threadIdx.x; idx < H * 20; idx += kGraphWaves * 64) w1s[idx] = a.w1[idx];
     // the weight stage's small operands go through LDS as well (requested now: no L2 round trip behind the graph stage,
@@ -546,22 +548,34 @@ graph_kernel(GraphArgs a) {
             const float xj = x[j * 3], yj = x[j * 3 + 1], zj = x[j * 3 + 2];
             const float dx = xj - xi, dy = yj - yi, dz = zj - zi;
             dc[q] = dist2_rounded(dx, dy, dz);
-            dist[wave][sub][c] = dc[q];
+            // order by distance, ties by index: squared distances are non-negative floats, whose bit patterns order like
+            // unsigned integers; the atom itself gets the largest key, so it precedes no candidate
+            dkey[wave][sub][c] = c == self ? ~0ull : ((unsigned long long)__builtin_bit_cast(unsigned, dc[q]) << 32) | (unsigned)c;
             xs[wave][sub][c][0] = xj; xs[wave][sub][c][1] = yj; xs[wave][sub][c][2] = zj;
         }
     }
     for (int sl = l; sl < KP; sl += LPA) row[wave][sub * KP + sl] = -1;
+    SM_STAMP(a.stamps, 1);
     __syncthreads();                       // w1s staged; this wave's rows of distances written
+    SM_TICK(a.stamps, 2);
     int rank[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) rank[q] = 0;
+    // candidate chunks the wave's molecules really have (a wave-uniform bound: the compare chain of an empty chunk is pure
+    // waste, and with six waves per SIMD this loop is bound by vector issue: its phase 6.0 -> 2.8 us for molecules below
+    // 32 atoms; taking the distances from the candidates' registers by v_readlane instead of the LDS row changes nothing,
+    // packing (distance, index) into one 64-bit key -- one compare instead of five -- does)
+    int nq_w = __builtin_amdgcn_readlane((cnt + LPA - 1) / LPA, 0);
+    if constexpr (APW > 1) nq_w = max(nq_w, __builtin_amdgcn_readlane((cnt + LPA - 1) / LPA, LPA));
+    unsigned long long kc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) kc[q] = ((unsigned long long)__builtin_bit_cast(unsigned, dc[q]) << 32) | (unsigned)(l + LPA * q);
     for (int o = 0; o < cnt; ++o) {
-        const float d_o = dist[wave][sub][o];
-        const bool other = o != self;
+        const unsigned long long k_o = dkey[wave][sub][o];      // one 64-bit compare per candidate: (d_o, o) < (d_c, c)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int c = l + LPA * q;
-            rank[q] += other && (o != c) && (d_o < dc[q] || (d_o == dc[q] && o < c));
+            if (q >= nq_w) break;
+            rank[q] += k_o < kc[q];
         }
     }
 #pragma unroll
@@ -572,6 +586,7 @@ graph_kernel(GraphArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    SM_TICK(a.stamps, 3);
     if (valid)
         for (int sl = l; sl < KP; sl += LPA) a.nbr[(size_t)i * KP + sl] = row[wave][sub * KP + sl];
     // ---- edge weights of the wave's slots: edge_weight_kernel's tile (column n = slot n of the wave's atoms) ----
@@ -604,7 +619,9 @@ graph_kernel(GraphArgs a) {
             for (int s5 = 0; s5 < 5; ++s5) acc = mfma16(w1s[(16 * t + n) * 20 + 4 * s5 + g], rb[s5], acc);
             hid[4 * t] = acc[0]; hid[4 * t + 1] = acc[1]; hid[4 * t + 2] = acc[2]; hid[4 * t + 3] = acc[3];
         }
+        SM_TICK(a.stamps, 4);
         ln_relu_dlayout<NT>(hid, prm[1], prm[2], g);
+        SM_TICK(a.stamps, 5);
         float p = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -614,6 +631,7 @@ graph_kernel(GraphArgs a) {
         p = sum_groups(p) + b2;
         if (g == 0 && in_range) a.ew[(size_t)ia * KP + slot % KP] = ok ? 1.0f / (1.0f + expf(-p)) : 0.f;
     }
+    SM_STAMP(a.stamps, 6);
 }
 
 // ---------------------------------------------------------------------------------------------

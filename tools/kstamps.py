@@ -35,6 +35,7 @@ names = {0: ["start", "weights+tile0 loaded", "all tiles done (stores drained)",
 names[1] = ["start", "both images in LDS (barrier)", "key: hidden fragments ready", "key: GEMM2 + softmax done", "value: hidden fragments ready", "value: GEMM2 + sums + stores issued", "(serial build) image DMA landed", "(serial build) nbr + x loaded"]      # sm_edge16.h
 names[2] = names[1]
 names[3] = ["start", "W1 + [att|h] fragments staged (barrier)", "GEMM1 -> pre (barrier)", "normalise (barrier)", "GEMM2 + h' (barrier)", "follow GEMM1s (barrier)", "normalise x2 (barrier)", "follow GEMM2s + stores drained"]
+names[4] = ["start", "span, coordinates, distances -> LDS (drained)", "barrier (weights staged)", "rank loop + neighbour row", "weight MLP: first Linear (fp32 MFMA)", "LayerNorm", "dot, sigmoid, stores drained", "-"]     # graph_kernel
 nm = names[a.sel if a.sel in names else 1]
 for k in range(8):
     col = st[:, k]; col = col[col > 0]
