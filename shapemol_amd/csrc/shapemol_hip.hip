@@ -924,7 +924,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             cur_h = dst;
             // per-node halves of the edge MLPs' first Linear: h2x of this layer | x2h of the next one
             if (!lin_fused && launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->P(Dl.lin6_img), c->P(Dl.lin16_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
-                                 c->preAB, 8 * H, lin_tiles, n, nullptr)) return 1;
+                                 c->preAB, 8 * H, lin_tiles, n, (c->kstamp_sel == 0 && l == 0) ? c->kstamps : nullptr)) return 1;
         }
         float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
         bool vn_done = false, stats_done = false;

@@ -42,6 +42,7 @@ node_linear16_kernel(NodeLinArgs a, int *range_flag) {
     const int n_ct = (a.n_atoms + 15) / 16;
     const int ct0 = ag * a.tiles_per_group, ct1 = min(ct0 + a.tiles_per_group, n_ct);
 
+    SM_TICK(a.stamps, 0);
     u32x4 w[2][NB];
     {
         const u32x4 *wi = reinterpret_cast<const u32x4 *>(a.wimg) + (size_t)ot * 2 * NB * 64 + lane;
@@ -64,7 +65,9 @@ node_linear16_kernel(NodeLinArgs a, int *range_flag) {
             u32x4 *dst = frag + ((size_t)(sc * 2) * NB + sb) * 64 + sl;
             dst[0] = hi; dst[NB * 64] = lo;
         }
+        SM_TICK(a.stamps, 1);
         __syncthreads();
+        SM_TICK(a.stamps, 2);
         for (int c = 0; c < nc; c += 2) {                           // two tiles at a time: independent MFMA chains
             const bool two = c + 1 < nc;
             const int atom0 = (cb + c) * 16 + n, atom1 = atom0 + 16;
@@ -87,7 +90,9 @@ node_linear16_kernel(NodeLinArgs a, int *range_flag) {
             if (ot_ok && atom0 < a.n_atoms) stg4(a.out + (size_t)atom0 * a.ld_out + 16 * ot + 4 * g, float4{acc0[0], acc0[1], acc0[2], acc0[3]});
             if (ot_ok && two && atom1 < a.n_atoms) stg4(a.out + (size_t)atom1 * a.ld_out + 16 * ot + 4 * g, float4{acc1[0], acc1[1], acc1[2], acc1[3]});
         }
+        SM_TICK(a.stamps, 3);
     }
+    SM_STAMP(a.stamps, 4);
 }
 
 template <int H>

@@ -30,7 +30,7 @@ st = m.debug_read("kstamps", (4096 * 16, 8), np.uint64).astype(np.int64)
 st = st[st[:, 0] > 0]
 t0 = st[:, 0].min()
 print(f"waves stamped: {len(st)}; all times in us relative to the earliest stamp 0")
-names = {0: ["start", "weights+tile0 loaded", "all tiles done (stores drained)", "-", "-", "-", "-", "-"],
+names = {0: ["start", "weights requested, rows loaded + split -> LDS", "barrier", "all tiles' products + stores issued", "stores drained", "-", "-", "-"],
          1: ["start", "K image in LDS (barrier 1)", "key: rbf + gathered rows summed", "key: GEMM1 (fp32 MFMA)", "key: LayerNorm+ReLU", "key: split", "key: GEMM2+softmax+alpha stores issued", "V image swapped (2 barriers)"]}
 names[1] = ["start", "both images in LDS (barrier)", "key: hidden fragments ready", "key: GEMM2 + softmax done", "value: hidden fragments ready", "value: GEMM2 + sums + stores issued", "(serial build) image DMA landed", "(serial build) nbr + x loaded"]      # sm_edge16.h
 names[2] = names[1]
