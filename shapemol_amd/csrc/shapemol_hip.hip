@@ -830,6 +830,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         pa.lin_img6 = c->P(c->node_f16 ? D0.pre16_x2h : D0.pre6_x2h); pa.add_mol = c->add0; pa.pre_out = c->pre0;
         pa.n_lin_tiles = nlay > 0 ? 4 * (H / 16) : 0; pa.ld_add = 4 * H; pa.ld_out = 4 * H;
         pa.n_atoms = n; pa.C = C; pa.D = D; pa.t_first = t_first; pa.bn_acc_len = ae.bn_acc_len;
+        pa.stamps = c->kstamp_sel == 5 ? c->kstamps : nullptr;
         const int n_ct = (n + 15) / 16;
         if (c->node_f16) LAUNCH("node_prologue", SMK(node_prologue16_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
                                                    2 * Chain16Lds<H>::FRAG * 16 + Chain16Lds<H>::PRE * 4, s, pa, c->status + ST_RANGE));

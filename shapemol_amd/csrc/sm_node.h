@@ -735,6 +735,7 @@ struct NodePrologueArgs {
     float *pre_out;               // [N][ld_out]
     int n_lin_tiles, ld_add, ld_out;
     int n_atoms, C, D, t_first, bn_acc_len;
+    unsigned long long *stamps;   // diagnostic build only
 };
 
 template <int H>

@@ -418,6 +418,7 @@ x2h_chain16_kernel(Edge16Args e, NodeChainArgs a, int *range_flag) {
 template <int H>
 __global__ void __launch_bounds__(H * 4)
 node_prologue16_kernel(NodePrologueArgs a, int *range_flag) {
+    SM_TICK(a.stamps, 0);
     using L = Chain16Lds<H>;
     using N16 = Node16<H>;
     constexpr int NT = H / 16, NB = H / 32, CC = CHAIN_COLS, XS = L::XS;
@@ -475,7 +476,9 @@ node_prologue16_kernel(NodePrologueArgs a, int *range_flag) {
     }
     if (a.n_lin_tiles > 0) N16::template load_w<NB>(a.lin_img6, ot, lane, wl);
     const float4 b1 = ldg4(a.q.b1 + f0);
+    SM_TICK(a.stamps, 1);
     __syncthreads();
+    SM_TICK(a.stamps, 2);
 
     // ---- stage 1: first Linear of the query MLP; the per-node linear outputs of the edge MLPs ------------
     {
@@ -508,9 +511,12 @@ node_prologue16_kernel(NodePrologueArgs a, int *range_flag) {
         if (more2) N16::template load_w<NB>(a.lin_img6, tile + 2 * NT, lane, wl);
         if (more1) lin_tile(tile + NT, wn);
     }
+    SM_TICK(a.stamps, 3);
     __syncthreads();
+    SM_TICK(a.stamps, 4);
     N16::normalise(pre0, NODE_LN_RELU, a.q.ln_g, a.q.ln_b, fhid, ot, lane, range_flag);
     __syncthreads();
+    SM_TICK(a.stamps, 5);
     if (onq) {
         const float4 b = ldg4(a.q.b2 + f0);
         f32x4 acc[CC];
@@ -521,4 +527,5 @@ node_prologue16_kernel(NodePrologueArgs a, int *range_flag) {
         for (int c = 0; c < CC; ++c)
             if (atom_ok(c)) stg4(a.q.out + (size_t)atom_of(c) * a.q.ld_out + f0, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
     }
+    SM_STAMP(a.stamps, 6);
 }
