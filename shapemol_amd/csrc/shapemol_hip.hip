@@ -444,6 +444,7 @@ struct shapemol_ctx {
     int KP = 8;
     float *d_img = nullptr;
     float *ttab = nullptr;      // [T][D] time-embedding table (built once)
+    float *etab = nullptr;      // [T][C][H] atom embedding of every (timestep, atom type) pair (built once)
     DevModel dm;
     // workspace
     int64_t capN = 0, capB = 0;
@@ -824,7 +825,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
     if (fused_prologue) {
         const DevLayer &D0 = c->dm.layer[0];
         NodePrologueArgs pa{};
-        pa.emb_wT = c->P(c->dm.embwT); pa.emb_b = ae.b; pa.v = v_in; pa.mol_of = c->mol_of; pa.ttab = c->ttab; pa.t_mol = c->t_mol;
+        pa.emb_wT = c->P(c->dm.embwT); pa.emb_b = ae.b; pa.v = v_in; pa.mol_of = c->mol_of; pa.ttab = c->ttab; pa.etab = c->etab; pa.t_mol = c->t_mol;
         pa.step_ptr = ae.step_ptr; pa.step_cur = ae.step_cur; pa.bn_acc = c->bn_acc; pa.h_out = c->h_a;
         pa.q = follow_of(c, D0.q_x2h, NODE_LN_RELU, c->q_x, H, H);
         pa.lin_img6 = c->P(c->node_f16 ? D0.pre16_x2h : D0.pre6_x2h); pa.add_mol = c->add0; pa.pre_out = c->pre0;
@@ -1097,6 +1098,12 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
         TimeTableArgs ta{c->P(dm.te1w), c->P(dm.te1b), c->P(dm.te2w), c->P(dm.te2b), c->ttab, T, cfg->time_emb_dim};
         hipLaunchKernelGGL(time_table_kernel, dim3((T + 63) / 64), dim3(64), 0, nullptr, ta);
         if (hipDeviceSynchronize() != hipSuccess) { hipFree(c->ttab); hipFree(c->d_img); delete c; return fail("time table kernel failed"); }
+        // ... and the atom embedding of every (timestep, atom type) pair
+        const int C = cfg->num_classes;
+        if (hipMalloc((void **)&c->etab, (size_t)T * C * H * sizeof(float)) != hipSuccess) { hipFree(c->ttab); hipFree(c->d_img); delete c; return fail("hipMalloc(embedding table) failed"); }
+        const int items = T * C * (H / 4);
+        hipLaunchKernelGGL(emb_table_kernel, dim3((items + 255) / 256), dim3(256), 0, nullptr, c->P(dm.embwT), c->P(dm.embb), c->ttab, c->etab, T, C, cfg->time_emb_dim, H);
+        if (hipDeviceSynchronize() != hipSuccess) { hipFree(c->etab); hipFree(c->ttab); hipFree(c->d_img); delete c; return fail("embedding table kernel failed"); }
     }
     if (c->hid_max > 6.0e4f) c->edge_bf16 = 1;      // hidden activations could overflow fp16: exactly split bf16 kernels
     *out = c;
@@ -1111,6 +1118,7 @@ void shapemol_destroy(shapemol_ctx *c) {
     for (auto &r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (void *p : c->allocs) hipFree(p);
     hipFree(c->ttab);
+    hipFree(c->etab);
     hipFree(c->d_img);
     if (c->g_cloud) hipFree(c->g_cloud);
     if (c->bn_run) hipFree(c->bn_run);

@@ -229,6 +229,25 @@ __global__ void time_table_kernel(TimeTableArgs a) {
     }
 }
 
+// The atom embedding of every (timestep, atom type) pair, built once: etab[t][v][:] = (b + W[:, v]) + sum_k W[:, C + k] te_t[k],
+// k ascending -- the arithmetic of the prologue's embedding stage, which then reads one 512-byte row per atom instead of
+// running the sum behind three dependent loads (step counter -> time row; atom type -> weight row).  T x C x H floats (7.7 MB).
+__global__ void emb_table_kernel(const float *emb_wT, const float *emb_b, const float *ttab, float *etab, int T, int C, int D, int H) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;         // (t, v, f / 4)
+    const int q4 = H / 4;
+    if (idx >= T * C * q4) return;
+    const int f = 4 * (idx % q4), v = (idx / q4) % C, t = idx / (q4 * C);
+    const float *te = ttab + (size_t)t * D;
+    const float4 bb = ldg4(emb_b + f), wv = ldg4(emb_wT + (size_t)v * H + f);
+    float y[4] = {bb.x + wv.x, bb.y + wv.y, bb.z + wv.z, bb.w + wv.w};
+    for (int k = 0; k < D; ++k) {
+        const float4 wk = ldg4(emb_wT + (size_t)(C + k) * H + f);
+        const float tk = te[k];
+        y[0] += wk.x * tk; y[1] += wk.y * tk; y[2] += wk.z * tk; y[3] += wk.w * tk;
+    }
+    stg4(etab + ((size_t)t * C + v) * H + f, float4{y[0], y[1], y[2], y[3]});
+}
+
 // ligand_atom_emb(cat[one_hot(v), time_emb[batch]])  (molopt_score_model.py:292-301) + the
 // per-evaluation bookkeeping: latch the step counter, clear the batch-norm accumulators.
 struct AtomEmbArgs {

@@ -724,6 +724,7 @@ struct NodePrologueArgs {
     const int64_t *v;             // [N]
     const int *mol_of;
     const float *ttab;            // [T][D]
+    const float *etab;            // [T][C][H] embedding of every (timestep, atom type) pair (emb_table_kernel), or nullptr
     const int *t_mol;             // [B] timestep per molecule (score API)
     const int *step_ptr;          // sampling: device step counter (t = t_first - step), else nullptr
     int *step_cur;

@@ -452,6 +452,11 @@ node_prologue16_kernel(NodePrologueArgs a, int *range_flag) {
         const int vi = min(max((int)a.v[at], 0), a.C - 1);       // out-of-range types are flagged by v_check_kernel
         const int fa = 32 * sb + 4 * (sl >> 4);
         float vv[8];
+        if (a.etab) {                                         // the precomputed row of (t, v): the same sum, done once
+            const float *row = a.etab + ((size_t)t * a.C + vi) * H + fa;
+            const float4 r0 = ldg4(row), r1 = ldg4(row + 16);
+            vv[0] = r0.x; vv[1] = r0.y; vv[2] = r0.z; vv[3] = r0.w; vv[4] = r1.x; vv[5] = r1.y; vv[6] = r1.z; vv[7] = r1.w;
+        } else
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {                      // y = (b + W[:, v]) + sum_k W[:, C + k] te[k], k ascending
             const int f = fa + 16 * hf;
