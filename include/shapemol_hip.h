@@ -94,7 +94,7 @@ typedef struct shapemol_traj {
  *   models/molopt_score_model.py:662,99).  Otherwise noise is generated on the device
  *   (Philox4x32-10 keyed by `seed`, Box-Muller).
  *   out_pos (N,3) f32, out_v (N,) i64: final state.  use_graph != 0 replays a captured hipGraph of one
- *   reverse step (and of eight steps back to back).  The capture depends on (n_atoms, n_mols) only: seed,
+ *   reverse step (and of twenty steps back to back).  The capture depends on (n_atoms, n_mols) only: seed,
  *   noise and trajectory pointers are passed through device memory, so chains with new seeds or new result
  *   buffers replay the same executable. */
 int shapemol_sample(shapemol_ctx *ctx, const float *d_init_pos, const int64_t *d_init_v,

@@ -35,7 +35,7 @@ int fail(const std::string &m) { g_err = m; return 1; }
 
 constexpr int kEdgeThreadsDefault = 768;
 #ifndef SM_GRAPH_UNROLL
-#define SM_GRAPH_UNROLL 8
+#define SM_GRAPH_UNROLL 20
 #endif
 constexpr int kGraphUnroll = SM_GRAPH_UNROLL;   // reverse steps per graph launch
 
@@ -1203,7 +1203,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
         key.N = N; key.B = B; key.guided = c->g_points > 0; key.fold = vn_fold_ok(c, (int)N);
         key.gfuse = c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap;
         // two executables: one reverse step, and kGraphUnroll steps back to back (the gap between two graph launches,
-        // ~5 us, is then paid once per kGraphUnroll steps); every step reads its index from the device-side counter
+        // ~8 us, is then paid once per kGraphUnroll steps); every step reads its index from the device-side counter
         auto capture = [&](int n_steps, hipGraphExec_t *exec) -> int {
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
