@@ -215,7 +215,7 @@ class ScorePosNet3D(nn.Module):
         return time_step, torch.ones_like(time_step).float() / self.num_timesteps
 
     def _table(self, name):
-        return self.state_dict()[name]
+        return getattr(self, name).detach()        # schedule vectors are registered on the module itself (top-level state-dict keys)
 
     def _v_mix(self, log_x, log_keep, log_drop):
         a, b = log_x + log_keep, log_drop - float(np.log(self.num_classes))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Measurement of the two widened rows on the GPU box, with their CPU counterparts timed beside:
+"""Measurement of the widened rows (SURVEY.md section 8 f2, f3 and the validation half of f4) on the GPU box, with their CPU counterparts timed beside:
 the frozen shape encoder (shapes/s, against the torch-CPU oracle) and the point-cloud guidance (us per guided step against
 the reference's own algorithm: numpy + sklearn KD-tree on the host plus the D2H / H2D copies it needs).
     python tools/aux_bench.py > profiles/r02_final/aux_bench.json"""
@@ -107,4 +107,38 @@ out["pointcloud_guidance"] = {"atoms": n, "cloud_points": 512, "standalone_call_
                               "host_reference_algorithm_us": round(t_host * 1e6, 1),
                               "chain_us_per_step_unguided": round(plain * 1e6, 1), "chain_us_per_step_guided": round(guided * 1e6, 1),
                               "in_chain_cost_us_per_guided_step": round((guided - plain) * 1e6, 1)}
+# ---- validation loss (f4, the half validate() needs): ten time steps per batch as scripts/train_diffusion.py:178 ----------
+from oracle import shapemol_oracle as O  # noqa: E402
+from util import model_cfg  # noqa: E402
+cfg = model_cfg()
+sdn = synth.synthetic_state_dict(cfg, seed=7)
+sdn.update(synth.running_stats(m.dims.L, m.dims.heads, 23))
+mv = shapemol_amd.ScorePosNet3D(cfg, 15)
+mv.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+mv = mv.to(DEV).eval()
+pos0 = torch.from_numpy((synth.hash_normal((n, 3), 501, 41) * 1.5).astype(np.float32)).to(DEV)
+ts = np.linspace(0, 999, 10).astype(int)
+def validate_batch():
+    tot = 0.0
+    with torch.no_grad():
+        for t in ts:
+            r = mv.get_diffusion_loss(pos0, args[1], args[2], args[3], time_step=torch.full((256,), int(t), dtype=torch.long, device=DEV), eval_mode=True)
+            tot += float(r["loss"])
+    return tot
+validate_batch()
+t0 = time.perf_counter()
+validate_batch()
+torch.cuda.synchronize()
+t_dev = time.perf_counter() - t0
+sd_o, dm_o = O.state_dict_from_numpy(sdn), O.Dims(cfg)
+noise = synth.hash_normal((n, 3), 502, 41); uu = synth.hash_uniform((n, 15), 503, 41)
+torch.set_num_threads(16)
+t0 = time.perf_counter()
+O.diffusion_loss(sd_o, dm_o, pos0.cpu(), args[1].cpu(), args[2].cpu(), torch.from_numpy(bb["shape"]), torch.full((256,), 500, dtype=torch.long),
+                 torch.from_numpy(noise), torch.from_numpy(uu), bn_eval=True)
+t_cpu = time.perf_counter() - t0
+out["validation_loss"] = {"molecules": 256, "atoms": n, "time_steps_per_batch": 10, "device_ms_per_batch": round(t_dev * 1e3, 2),
+                          "device_ms_per_evaluation": round(t_dev * 1e2, 3), "cpu_oracle_ms_per_evaluation": round(t_cpu * 1e3, 1),
+                          "cpu_threads": torch.get_num_threads(),
+                          "note": "get_diffusion_loss(eval_mode=True) as validate() calls it, float(loss) read back after every evaluation as the script does"}
 print(json.dumps(out, indent=1))
