@@ -497,8 +497,10 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
                 v_s2 += (double)nrm * (double)nrm;
             }
         }
+        SM_TICK(a.stamps, 6);
         if (lane < 32) { vn_red[(wave * 32 + lane) * 2] = v_s1; vn_red[(wave * 32 + lane) * 2 + 1] = v_s2; }
         __syncthreads();
+        SM_TICK(a.stamps, 7);
         if (threadIdx.x < HD) {
             double s1 = 0.0, s2 = 0.0;
             for (int w = 0; w < nwave; ++w)

@@ -33,7 +33,7 @@ print(f"waves stamped: {len(st)}; all times in us relative to the earliest stamp
 names = {0: ["start", "weights requested, rows loaded + split -> LDS", "barrier", "all tiles' products + stores issued", "stores drained", "-", "-", "-"],
          1: ["start", "K image in LDS (barrier 1)", "key: rbf + gathered rows summed", "key: GEMM1 (fp32 MFMA)", "key: LayerNorm+ReLU", "key: split", "key: GEMM2+softmax+alpha stores issued", "V image swapped (2 barriers)"]}
 names[1] = ["start", "both images in LDS (barrier)", "key: hidden fragments ready", "value: hidden fragments ready", "key: GEMM2 + softmax done", "value: GEMM2 + sums + stores issued", "(serial build) image DMA landed", "(serial build) nbr + x loaded"]      # sm_edge16.h
-names[2] = names[1]
+names[2] = names[1][:6] + ["VN-linear of the wave's atoms", "workgroup barrier (then batch sums -> atomics)"]      # h2x
 names[3] = ["start", "W1 + [att|h] fragments staged (barrier)", "GEMM1 -> pre (barrier)", "normalise (barrier)", "GEMM2 + h' (barrier)", "follow GEMM1s (barrier)", "normalise x2 (barrier)", "follow GEMM2s + stores drained"]
 names[4] = ["start", "span, coordinates, distances -> LDS (drained)", "barrier (weights staged)", "rank loop + neighbour row", "weight MLP: first Linear (fp32 MFMA)", "LayerNorm", "dot, sigmoid, stores drained", "-"]     # graph_kernel
 names[5] = ["start", "embedding -> fragments, weights requested", "barrier", "query GEMM1 + 4H per-node products issued", "barrier", "normalise (barrier)", "query GEMM2 + stores drained", "-"]     # node_prologue16_kernel
