@@ -693,13 +693,21 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
         if (one || c->edge_tiles == 0) {
             // larger batches (edge_tiles = 0): several launches of the straight-line instantiation, each over a slice of
             // grid x waves jobs (no spills, full overlap inside a launch; the image fill is paid per slice)
-            const int per = grid * waves;
+            // ... of equal size: the jobs are spread evenly over the fewest launches that can hold them (a last slice that
+            // is nearly empty costs a full launch floor)
+            int ws = waves, gs = grid;
+            if (!one) {
+                const int nsl = (njobs + c->num_cu * 12 - 1) / (c->num_cu * 12), target = (njobs + nsl - 1) / nsl;
+                ws = std::max(4, std::min(12, (target + c->num_cu - 1) / c->num_cu));
+                gs = std::max(1, std::min(c->num_cu, (target + ws - 1) / ws));
+            }
+            const int per = gs * ws;
             for (int base = 0; base < njobs; base += per) {
                 Edge16Args b = a;
-                b.job_base = base; b.job_end = std::min(njobs, base + per); b.nwave = waves;
-                const int g2 = std::max(1, std::min(grid, (b.job_end - base + waves - 1) / waves));
-                if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(g2), dim3(waves * 64), shm, s, b));
-                else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(g2), dim3(waves * 64), shm, s, b));
+                b.job_base = base; b.job_end = std::min(njobs, base + per); b.nwave = ws;
+                const int g2 = std::max(1, std::min(gs, (b.job_end - base + ws - 1) / ws));
+                if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(g2), dim3(ws * 64), shm, s, b));
+                else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(g2), dim3(ws * 64), shm, s, b));
             }
             return 0;
         }
