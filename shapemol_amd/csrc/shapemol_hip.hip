@@ -696,18 +696,20 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
             // ... of equal size: the jobs are spread evenly over the fewest launches that can hold them (a last slice that
             // is nearly empty costs a full launch floor)
             int ws = waves, gs = grid;
-            if (!one) {
+            if (!one && c->edge_threads == 0) {      // (an explicit edge_waves option keeps its wave count)
                 const int nsl = (njobs + c->num_cu * 12 - 1) / (c->num_cu * 12), target = (njobs + nsl - 1) / nsl;
                 ws = std::max(4, std::min(12, (target + c->num_cu - 1) / c->num_cu));
                 gs = std::max(1, std::min(c->num_cu, (target + ws - 1) / ws));
             }
             const int per = gs * ws;
+            const size_t shm_s = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
+                                 + (H2X ? (size_t)vn_red_doubles(ws, H / 8) * 8 + (size_t)ws * apj * 48 * 4 : (a.vf.enable ? kVnFoldBytes : 0));
             for (int base = 0; base < njobs; base += per) {
                 Edge16Args b = a;
                 b.job_base = base; b.job_end = std::min(njobs, base + per); b.nwave = ws;
                 const int g2 = std::max(1, std::min(gs, (b.job_end - base + ws - 1) / ws));
-                if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(g2), dim3(ws * 64), shm, s, b));
-                else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(g2), dim3(ws * 64), shm, s, b));
+                if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(g2), dim3(ws * 64), shm_s, s, b));
+                else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(g2), dim3(ws * 64), shm_s, s, b));
             }
             return 0;
         }
