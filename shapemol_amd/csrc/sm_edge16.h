@@ -211,6 +211,10 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
         const float *pi = a.pre + (size_t)(SM_ABL(17) ? 0 : atom) * a.ld_pre + 2 * H, *pj = a.pre + (size_t)(SM_ABL(17) ? 0 : jn) * a.ld_pre + 3 * H;
 #pragma unroll
         for (int t = 0; t < NT; ++t) { gav[t] = ldg4(pi + 16 * t + 4 * g); gbv[t] = ldg4(pj + 16 * t + 4 * g); }
+    };
+    // the query row: requested once the value rows have been consumed (it is first used by the key phase, after the value
+    // MLP's hidden layer), so that it does not hold 32 registers beside them
+    auto request_q = [&]() {
         const float *qrow = a.q + (size_t)atom * H + 4 * g;
 #pragma unroll
         for (int t = 0; t < NT; ++t) qv[t] = ldg4(qrow + 16 * t);
@@ -351,9 +355,9 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
         if (!SM_ABL(18)) {
             hidden(imk, IMK{}, ga, gb, rh, rl, kh, kl, request_2);
             SM_TICK(a.stamps, 2);
-            hidden(imv, IMV{}, gav, gbv, rh, rl, vh, vl, []() {});
+            hidden(imv, IMV{}, gav, gbv, rh, rl, vh, vl, request_q);
         } else {
-            request_2();
+            request_2(); request_q();
 #pragma unroll
             for (int b = 0; b < NT / 2; ++b) {
                 kh[b] = u32x4{__builtin_bit_cast(unsigned, ga[b].x + gb[b].x), rh[1], rh[2], rl[0]}; kl[b] = rl; vh[b] = kh[b];
