@@ -41,6 +41,10 @@ F16_MFMA_PEAK_TFLOPS = 2500.0      # dense f16 / bf16 matrix peak (same guide)
 HBM_PEAK_GBS = 8000.0              # HBM3E peak (same guide)
 PROFILE_DIR = "r02_final"          # profiles/<dir>/pmc_traffic*.json hold the PMC traffic of the kernels timed here
 CHAIN_STEPS = 1000                 # the metric is quoted for 1000-step chains
+# what the arithmetic is: fp32 inputs, outputs, accumulators and vector work; the matrix products take their fp32 operands as
+# two f16 pieces each (hi + lo, 22 significand bits) and sum three piece products in fp32.  `exact_mode` on the JSON line times
+# the same chain with every operand split exactly (three bf16 pieces, six products: fp32-exact products).
+DTYPE = "f32 (matrix operands as 2 x f16 pieces = 22 bits, fp32 accumulate)"
 
 
 def executed_flops_per_atom_step(H, L, k, G=20, heads=16, C=15, S=32):
@@ -89,8 +93,13 @@ def main():
     ap.add_argument("--knn", type=int, default=0, help="override the model's k (configs[4]: 32)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: still initialise a 1-rank process group of --backend and run the final gather of the molecules "
+                         "through its packing / all_gather_into_tensor / unpacking path (exercises the RCCL branch on a one-GPU box)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--cpu-steps", type=int, default=20, help="reverse steps of the CPU oracle to time (0 = skip)")
+    ap.add_argument("--exact-steps", type=int, default=-1, help="reverse steps of the exact-operand chain (extra field `exact_mode`; "
+                                                                "-1 = as --steps, 0 = skip)")
     ap.add_argument("--no-traj", action="store_true", help="do not keep per-step trajectories")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--concurrent", type=int, default=2,
@@ -113,8 +122,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -132,6 +144,8 @@ def main():
         name, val = kv.split("=")
         model.set_option(name, int(val))
     steps, warm = min(args.steps, CHAIN_STEPS), max(0, min(args.warmup, CHAIN_STEPS))
+    if args.exact_steps < 0:
+        args.exact_steps = steps
 
     bb = synth.synthetic_batch(args.batch, seed=2021 + rank, atoms_range=atoms_range)     # every rank owns a different batch
     n_atoms = len(bb["batch"])
@@ -150,16 +164,18 @@ def main():
         runner.run(warm, seed=11, use_graph=use_graph)
         runner.synchronize()
         if dist is not None:
-            gather_molecules(runner.out_pos, runner.out_v, counts)
+            gather_molecules(runner.out_pos, runner.out_v, counts, _single_rank_too=True)
     log(f"timing {steps} steps")
     barrier()
     t0 = time.perf_counter()
     runner.run(steps, seed=12, use_graph=use_graph)
     runner.synchronize()
     if dist is not None:
-        gather_molecules(runner.out_pos, runner.out_v, counts)
+        g_pos, g_v, g_counts = gather_molecules(runner.out_pos, runner.out_v, counts, _single_rank_too=True)
     barrier()
     elapsed = time.perf_counter() - t0
+    if dist is not None and world == 1:       # --force-collective: the gathered molecules are this rank's own, bit for bit
+        assert torch.equal(g_pos, runner.out_pos) and torch.equal(g_v, runner.out_v) and torch.equal(g_counts, counts)
     local_elapsed = elapsed
     if dist is not None:
         cdev = dev if args.backend == "nccl" else torch.device("cpu")
@@ -181,10 +197,10 @@ def main():
         rank_ms = [round(float(x), 4) for x in allr.cpu()]
 
     out = {
-        "metric": "molecules/sec (1000-step DDPM sample, batch 256)", "value": round(value, 3),
+        "metric": f"molecules/sec (1000-step DDPM sample, batch {args.batch})", "value": round(value, 3),
         "unit": "molecules/s", "n_gpus": world, "steps": steps, "warmup": warm,
         "ms_per_step": round(sec_per_step * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": (("BASELINE configs[1]: batch 256" if args.batch == 256 else
                                  ("BASELINE configs[2]/[3] size: batch 1024" if args.batch == 1024 else f"batch {args.batch}")) +
                                 (f" molecules of {atoms_range[0]}-{atoms_range[1]} atoms" if atoms_range else " MOSES-prior molecules (9-27 atoms)") +
@@ -192,7 +208,7 @@ def main():
                    "batch_per_gpu": args.batch, "atoms_per_gpu": n_atoms, "total_atoms": total_atoms,
                    "noise": "device Philox", "trajectories": "kept in HBM" if not args.no_traj else "off",
                    "launch": "hipGraph replay" if use_graph else "eager", "parallelism": f"dp{world} (whole batches per rank)",
-                   "ranks_seen": (dist.get_world_size() if dist is not None else 1), "ms_per_step_by_rank": rank_ms, **({"options": args.opt} if args.opt else {}),
+                   "ranks_seen": (dist.get_world_size() if dist is not None else 1), **({"collective": f"forced 1-rank {args.backend} gather"} if (dist is not None and world == 1) else {}), "ms_per_step_by_rank": rank_ms, **({"options": args.opt} if args.opt else {}),
                    "matrix_products": "edge and node MLPs: two-piece f16 operands (22 significand bits), three products per term, fp32 "
                                       "accumulate; everything else fp32 (options edge_bf16 = 1, node_f16 = 0: exactly split bf16 operands)"},
     }
@@ -290,6 +306,26 @@ def main():
                                         "note": "independent batch-256 chains (own batch-norm statistics each) on separate streams of one GPU"}
             log(f"concurrent chains: {out['concurrent_chains']}")
             del runners
+        # ---- the same chain with exactly split operands (fp32-exact products), driver-timed like `value` ----
+        if world == 1 and args.exact_steps > 0 and use_graph and not args.opt:
+            es = min(args.exact_steps, runner.max_steps)
+            model.set_option("edge_bf16", 1)
+            model.set_option("node_f16", 0)
+            try:
+                runner.run(max(1, min(warm, es)), seed=31, use_graph=True)       # re-captures the step graph with these kernels
+                runner.synchronize()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                runner.run(es, seed=32, use_graph=True)
+                runner.synchronize()
+                dte = (time.perf_counter() - t1) / es
+                out["exact_mode"] = {"value": round(args.batch / (CHAIN_STEPS * dte), 3), "unit": "molecules/s", "ms_per_step": round(dte * 1e3, 4),
+                                     "steps": es, "dtype": "f32 (matrix operands as 3 x bf16 pieces = 24 bits, exact; six products, fp32 accumulate)",
+                                     "options": ["edge_bf16=1", "node_f16=0"]}
+                log(f"exact mode: {out['exact_mode']}")
+            finally:
+                model.set_option("edge_bf16", 3)
+                model.set_option("node_f16", 1)
         # trajectory D2H cost (reported, never part of value)
         if not args.no_traj:
             torch.cuda.synchronize()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SHAPEMOL_ABI_VERSION 3
+#define SHAPEMOL_ABI_VERSION 4
 
 typedef struct shapemol_ctx shapemol_ctx;
 
@@ -117,6 +117,15 @@ int shapemol_set_guidance(shapemol_ctx *ctx, const double *h_cloud, int64_t n_po
  * cloud of shapemol_set_guidance; d_draws DEVICE (5,N) float64 or NULL (Philox(seed)). */
 int shapemol_guide_points(shapemol_ctx *ctx, float *d_pos, int64_t n_points, const double *d_draws, uint64_t seed, void *stream);
 
+/* The same as the reference's MODULE-level function pointcloud_shape_guidance(use_pointcloud_data, pred_ligand_pos, k=3,
+ * ratio=0.2) (models/molopt_score_model.py:699-740), which has no model object at hand: no context, the cloud comes with
+ * the call (h_cloud: HOST (n_cloud,3) float64, 3 .. 2048 points) on the CURRENT device; d_pos (n_atoms,3) f32 DEVICE is
+ * guided in place; `ratio` is the lower end of the pull fraction u * (0.8 - ratio) + ratio; d_draws / seed as above.
+ * Unlike the other entry points this one synchronises `stream` before it returns (it owns a temporary device block); the
+ * reference's function is synchronous as well (D2H copy, host KD-tree, H2D copy). */
+int shapemol_pointcloud_guidance(const double *h_cloud, int64_t n_cloud, double radius, double ratio, float *d_pos,
+                                 int64_t n_atoms, const double *d_draws, uint64_t seed, void *stream);
+
 /* Input validation happens on the device (no host synchronisation in _score/_sample): an unsorted or
  * out-of-range d_batch, an atom type outside [0, num_classes) or a time step outside [0, num_timesteps)
  * sets a sticky flag (the offending index is clamped, so nothing is read or written out of bounds).
@@ -126,6 +135,9 @@ int shapemol_guide_points(shapemol_ctx *ctx, float *d_pos, int64_t n_points, con
  * flags_out (may be NULL) receives the eight raw flags {barrier, batch, atom type, time step, fp16 range, 0...}.
  * The reference raises from the corresponding torch indexing ops (models/molopt_score_model.py:292-301). */
 int shapemol_status(shapemol_ctx *ctx, int32_t *flags_out);
+/* The same, synchronising only `stream` (the one the last _score/_sample of this context was enqueued on) instead of the whole
+ * device: chains of other contexts running beside it are not waited for. */
+int shapemol_status_stream(shapemol_ctx *ctx, int32_t *flags_out, void *stream);
 
 /* Evaluation-mode batch-norm (the module after .eval(): scripts/train_diffusion.py:172-173 puts it there for validate(),
  * models/shape_vn_layers.py:50-61 then normalises the vector norms with BatchNorm1d's running statistics instead of the

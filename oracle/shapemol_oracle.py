@@ -318,16 +318,17 @@ def diffusion_loss(sd, dm, pos, v, batch, shape, t, pos_noise, u, bn_eval=True, 
 
 
 @torch.no_grad()
-def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, keep_traj=True, guidance=None, bn_eval=False):
+def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, keep_traj=True, guidance=None, bn_eval=False, first_step=0):
     """Reverse chain t = T-1 ... T-num_steps with host-fed noise ``noise_fn(step) -> (eps, u)``
     (numpy or torch arrays; per step eps (N,3) first, then u (N,C), the reference's draw order).
+    first_step = s0 resumes a chain at reverse step s0 (t = T-1-s0) from the given state; noise_fn still counts from 0.
     guidance = (cloud, radius, grad_step, draws (S,5,N)): point-cloud guidance of the predicted x0 while t > grad_step
     (/root/reference/models/molopt_score_model.py:583-586)."""
     B = int(batch.max()) + 1
     shape = shape.view(B, -1, 3)
     pos, v = init_pos, init_v
     out = {k: [] for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj", "pos_cond_traj", "v_cond_traj")}
-    for s, i in enumerate(reversed(range(dm.T - num_steps, dm.T))):
+    for s, i in enumerate(reversed(range(dm.T - first_step - num_steps, dm.T - first_step))):
         t = torch.full((B,), i, dtype=torch.long)
         pr = score(sd, dm, pos, v, batch, shape, t, bn_eval=bn_eval)      # bn_eval: a module put in eval mode before sampling
         if guidance is not None and i > guidance[2]:

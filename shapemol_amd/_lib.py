@@ -11,13 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SHAPEMOL_LIB selects a diagnostic build (tools/ only), e.g. "stamps" or "abl1"
 _variant = os.environ.get("SHAPEMOL_LIB") or ("stamps" if os.environ.get("SHAPEMOL_STAMPS") == "1" else "")
 LIB_PATH = os.path.join(_HERE, f"libshapemol_hip_{_variant}.so" if _variant else "libshapemol_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = (
     "shapemol_abi_version", "shapemol_last_error", "shapemol_weight_count", "shapemol_create",
     "shapemol_destroy", "shapemol_reserve", "shapemol_score", "shapemol_sample",
     "shapemol_log_sample_categorical", "shapemol_set_option", "shapemol_debug_read",
-    "shapemol_profile_begin", "shapemol_profile_end", "shapemol_status", "shapemol_set_guidance", "shapemol_guide_points",
+    "shapemol_profile_begin", "shapemol_profile_end", "shapemol_status", "shapemol_status_stream", "shapemol_set_guidance", "shapemol_guide_points",
+    "shapemol_pointcloud_guidance",
     "shapemol_set_bn_running",
     "shapemol_se_weight_count", "shapemol_se_create", "shapemol_se_destroy", "shapemol_se_encode",
 )
@@ -81,9 +82,11 @@ def load():
     lib.shapemol_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     lib.shapemol_debug_read.restype = i64
     lib.shapemol_status.argtypes = [vp, vp]
+    lib.shapemol_status_stream.argtypes = [vp, vp, vp]
     lib.shapemol_set_bn_running.argtypes = [vp, vp, vp, i64]
     lib.shapemol_set_guidance.argtypes = [vp, vp, i64, C.c_double, i32, vp]
     lib.shapemol_guide_points.argtypes = [vp, vp, i64, vp, u64, vp]
+    lib.shapemol_pointcloud_guidance.argtypes = [vp, i64, C.c_double, C.c_double, vp, i64, vp, u64, vp]
     lib.shapemol_se_weight_count.restype = C.c_size_t
     lib.shapemol_se_weight_count.argtypes = [i32, i32, i32]
     lib.shapemol_se_create.argtypes = [i32, i32, i32, i32, vp, C.c_size_t, C.c_int, C.POINTER(vp)]

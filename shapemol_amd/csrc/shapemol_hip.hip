@@ -501,9 +501,10 @@ struct shapemol_ctx {
     // launch decisions taken from the max_mol_atoms hint (folded coordinate update, fused graph kernel)
     struct GraphKey { int64_t N = 0, B = 0; int guided = 0, fold = 0, gfuse = 0;
                       bool operator==(const GraphKey &o) const { return N == o.N && B == o.B && guided == o.guided && fold == o.fold && gfuse == o.gfuse; } } gkey{};
-    void drop_graphs() {      // a replay may still be in flight: drain the device before destroying the executables
-        if (!gexec && !gexec_u) return;
-        hipDeviceSynchronize();
+    hipStream_t gstream = nullptr; bool gstream_set = false;     // the stream the executables were last launched on
+    void drop_graphs() {      // a replay may still be in flight: drain it before destroying the executables (only the stream the
+        if (!gexec && !gexec_u) return;       // graphs ran on: another context's chain may be running beside, and must not be waited for)
+        if (!gstream_set || hipStreamSynchronize(gstream) != hipSuccess) hipDeviceSynchronize();
         if (gexec) { hipGraphExecDestroy(gexec); gexec = nullptr; }
         if (gexec_u) { hipGraphExecDestroy(gexec_u); gexec_u = nullptr; }
     }
@@ -1203,7 +1204,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
         if (DISPATCH_H(c, run_score<128>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v),
                        run_score<32>(c, s, c->x_state, c->v_state, N, B, true, t_first, c->pred_pos, nullptr, c->pred_v))) return 1;
         if (c->g_points > 0) {     // point-cloud shape guidance of the predicted x0 (steps with t > grad_step)
-            PcGuideArgs ga{c->pred_pos, c->g_cloud, c->chain_params, c->steps + 1, (int)N, (int)c->g_points, t_first, c->g_grad_step, c->g_radius};
+            PcGuideArgs ga{c->pred_pos, c->g_cloud, c->chain_params, c->steps + 1, (int)N, (int)c->g_points, t_first, c->g_grad_step, c->g_radius, 0.2};
             LAUNCH("pc_guidance", SMK(pc_guidance_kernel, dim3((N * 16 + 255) / 256), dim3(256), (size_t)c->g_points * 24, s, ga));
         }
         return DISPATCH_H(c, run_ddpm<128>(c, s, N), run_ddpm<32>(c, s, N));
@@ -1238,6 +1239,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
         // nothing to capture inside a later, timed chain
         if (!c->gexec_u && capture(kGraphUnroll, &c->gexec_u)) return 1;
         int st = 0;
+        c->gstream = s; c->gstream_set = true;
         for (; st + kGraphUnroll <= num_steps; st += kGraphUnroll) HIPCHK(hipGraphLaunch(c->gexec_u, s));
         for (; st < num_steps; ++st) HIPCHK(hipGraphLaunch(c->gexec, s));
     } else {
@@ -1350,8 +1352,46 @@ int shapemol_guide_points(shapemol_ctx *c, float *d_pos, int64_t N, const double
     ChainParams cp{};
     cp.seed = seed; cp.guide_draws = d_draws; cp.step_base = 0;
     LAUNCH("prep", SMK(set_chain_params_kernel, dim3(1), dim3(1), 0, s, c->chain_params, cp, c->steps));
-    PcGuideArgs ga{d_pos, c->g_cloud, c->chain_params, nullptr, (int)N, (int)c->g_points, c->g_grad_step + 1, c->g_grad_step, c->g_radius};
+    PcGuideArgs ga{d_pos, c->g_cloud, c->chain_params, nullptr, (int)N, (int)c->g_points, c->g_grad_step + 1, c->g_grad_step, c->g_radius, 0.2};
     LAUNCH("pc_guidance", SMK(pc_guidance_kernel, dim3((N * 16 + 255) / 256), dim3(256), (size_t)c->g_points * 24, s, ga));
+    return 0;
+}
+
+int shapemol_pointcloud_guidance(const double *h_cloud, int64_t n_points, double radius, double ratio, float *d_pos, int64_t N,
+                                 const double *d_draws, uint64_t seed, void *stream) {
+    if (!h_cloud || !d_pos || N < 1) return fail("shapemol_pointcloud_guidance: bad argument");
+    if (n_points < 3 || n_points > 2048) return fail("shapemol_pointcloud_guidance: the cloud needs 3 .. 2048 points (it is staged in LDS)");
+    if (!(radius > 0.0) || !(ratio >= 0.0 && ratio < 0.8)) return fail("shapemol_pointcloud_guidance: radius must be > 0, ratio in [0, 0.8)");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t cloud_bytes = (size_t)n_points * 3 * sizeof(double);
+    unsigned char *blk = nullptr;                       // [cloud | ChainParams | step counter]
+    HIPCHK(hipMalloc((void **)&blk, cloud_bytes + sizeof(ChainParams) + 16));
+    double *d_cloud = reinterpret_cast<double *>(blk);
+    ChainParams *d_cp = reinterpret_cast<ChainParams *>(blk + cloud_bytes);
+    int *d_step = reinterpret_cast<int *>(blk + cloud_bytes + sizeof(ChainParams));
+    hipError_t e = hipMemcpyAsync(d_cloud, h_cloud, cloud_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        ChainParams cp{};
+        cp.seed = seed; cp.guide_draws = d_draws; cp.step_base = 0;
+        hipLaunchKernelGGL(set_chain_params_kernel, dim3(1), dim3(1), 0, s, d_cp, cp, d_step);
+        PcGuideArgs ga{d_pos, d_cloud, d_cp, nullptr, (int)N, (int)n_points, 1, 0, radius, ratio};      // t_first - 0 > grad_step: always guided
+        hipLaunchKernelGGL(pc_guidance_kernel, dim3((N * 16 + 255) / 256), dim3(256), (size_t)n_points * 24, s, ga);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = hipStreamSynchronize(s);       // the block is freed below; the reference's function is synchronous too
+    hipFree(blk);
+    if (e != hipSuccess) return fail(std::string("shapemol_pointcloud_guidance: ") + hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(std::string("shapemol_pointcloud_guidance: ") + hipGetErrorString(e2));
+    return 0;
+}
+
+static int status_message(const int32_t (&f)[8]) {
+    if (f[ST_BATCH]) return fail("batch vector is not sorted ascending or names a molecule >= n_mols; results are invalid");
+    if (f[ST_ATOM_TYPE]) return fail("an atom type is outside [0, num_classes); results are invalid");
+    if (f[ST_TIME]) return fail("a time step is outside [0, num_timesteps); results are invalid");
+    if (f[ST_SPAN]) return fail("a molecule is larger than the max_mol_atoms hint says (folded coordinate update / fused graph kernel); results are invalid");
+    if (f[ST_RANGE]) return fail("an activation left the fp16 range of the two-piece f16 node kernels (|x| >= 6e4 or NaN); results are invalid: set option node_f16 = 0 (exactly split bf16 kernels)");
+    if (f[ST_VN_BARRIER]) return fail("grid barrier of the fused coordinate update timed out (workgroups not co-resident); results are invalid");
     return 0;
 }
 
@@ -1362,13 +1402,18 @@ int shapemol_status(shapemol_ctx *c, int32_t *flags_out) {
     HIPCHK(hipDeviceSynchronize());
     if (c->status) HIPCHK(hipMemcpy(f, c->status, sizeof(f), hipMemcpyDeviceToHost));
     if (flags_out) std::memcpy(flags_out, f, sizeof(f));
-    if (f[ST_BATCH]) return fail("batch vector is not sorted ascending or names a molecule >= n_mols; results are invalid");
-    if (f[ST_ATOM_TYPE]) return fail("an atom type is outside [0, num_classes); results are invalid");
-    if (f[ST_TIME]) return fail("a time step is outside [0, num_timesteps); results are invalid");
-    if (f[ST_SPAN]) return fail("a molecule is larger than the max_mol_atoms hint says (folded coordinate update / fused graph kernel); results are invalid");
-    if (f[ST_RANGE]) return fail("an activation left the fp16 range of the two-piece f16 node kernels (|x| >= 6e4 or NaN); results are invalid: set option node_f16 = 0 (exactly split bf16 kernels)");
-    if (f[ST_VN_BARRIER]) return fail("grid barrier of the fused coordinate update timed out (workgroups not co-resident); results are invalid");
-    return 0;
+    return status_message(f);
+}
+
+int shapemol_status_stream(shapemol_ctx *c, int32_t *flags_out, void *stream) {
+    if (!c) return fail("shapemol_status_stream: null ctx");
+    int32_t f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (c->status) HIPCHK(hipMemcpyAsync(f, c->status, sizeof(f), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flags_out) std::memcpy(flags_out, f, sizeof(f));
+    return status_message(f);
 }
 
 int shapemol_profile_begin(shapemol_ctx *c) {

@@ -955,6 +955,7 @@ struct PcGuideArgs {
     const int *step_cur;
     int n_atoms, n_points, t_first, grad_step;
     double radius;
+    double ratio;             // lower end of the pull fraction: u * (0.8 - ratio) + ratio (the reference's default: 0.2)
 };
 
 // Three nearest cloud points of p.  Every candidate is one 64-bit key: the bits of its squared distance (non-negative
@@ -1023,7 +1024,7 @@ __global__ void __launch_bounds__(256) pc_guidance_kernel(PcGuideArgs a) {
                 ph((uint32_t)atom, (uint32_t)step, (uint32_t)(100 + j), 0x9c1du, r);
                 u = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
             }
-            const double scalar = u * (0.8 - 0.2) + 0.2;           // np.random.random() * (0.8 - ratio) + ratio, ratio = 0.2
+            const double scalar = u * (0.8 - a.ratio) + a.ratio;   // np.random.random() * (0.8 - ratio) + ratio
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const double nearest = (cloud[t.i[0] * 3 + k] + cloud[t.i[1] * 3 + k] + cloud[t.i[2] * 3 + k]) / 3.0;

@@ -17,7 +17,7 @@ def shard_batches(num_batches, rank, world_size):
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
-def gather_molecules(pos, v, counts, group=None):
+def gather_molecules(pos, v, counts, group=None, _single_rank_too=False):
     """All-gather the final molecules of every rank.
 
     pos (N_r,3) f32, v (N_r,) i64, counts (B_r,) i64 atoms per molecule on this rank (a rank may own nothing).
@@ -25,8 +25,9 @@ def gather_molecules(pos, v, counts, group=None):
     Two collectives: one all-gather of the (N_r, B_r) sizes, then ONE padded ``all_gather_into_tensor`` of a packed
     int32 buffer per rank: [pos bits (3 max_n) | atom types (max_n) | counts (max_b)] -- atom types (< num_classes)
     and atom counts fit 32 bits, coordinates travel as their bit patterns."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return pos, v, counts
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _single_rank_too):
+        return pos, v, counts          # (_single_rank_too: tests and `bench.py --force-collective` push a 1-rank group through the
+                                       #  packing / all_gather_into_tensor / unpacking below, e.g. RCCL on a one-GPU box)
     ws = dist.get_world_size(group)
     out_dev = pos.device
     if dist.get_backend(group) == "gloo" and pos.is_cuda:      # rehearsals on one GPU (bench.py --backend gloo): collectives on the host

@@ -11,10 +11,11 @@ Same call surface as the reference (paths relative to the reference repository):
   * ``log_sample_categorical(logits)``                        models/molopt_score_model.py:98-104
 
 All arithmetic runs in libshapemol_hip.so (hand-written HIP for gfx950) through the C ABI of
-``include/shapemol_hip.h``; torch only owns device memory and streams here.  As in the
-reference's sampling script the module is used in *train mode* semantics: the VN batch-norm
-always normalises with the statistics of the current batch; ``eval()`` does not
-change that, and running statistics are not updated.
+``include/shapemol_hip.h``; torch only owns device memory and streams here.  The module's
+``training`` flag selects the VN batch-norm's statistics as ``nn.BatchNorm1d`` does: train mode
+(what the reference's sampling script runs in) normalises with the statistics of
+the current batch, ``eval()`` (what ``validate()`` switches to) with the running statistics of
+the state dict; the running statistics are read, never updated.
 There is no CPU path: tensors must live on a HIP device and the library must be built.
 """
 import ctypes as C
@@ -121,13 +122,28 @@ class ScorePosNet3D(nn.Module):
         take = lambda which: np.ascontiguousarray(np.stack([sd[key.format(l, which)].detach().cpu().numpy() for l in range(self.dims.L)]), np.float32)
         return take("mean"), take("var")
 
-    def _context(self, device):
-        """Create (or refresh after a weight change / device move) the library context."""
+    def _context(self, device, slot=0):
+        """Create (or refresh after a weight change / device move) the library context.  slot > 0: additional contexts over the
+        same weights (own workspace and captured graphs each), so that independent chains can be in flight side by side
+        (shapemol_amd.sampling keeps two)."""
         key = self._weights_key(device)
+        if slot != 0:
+            extra = self.__dict__.setdefault("_ctx_extra", {})
+            ent = extra.get(slot)
+            if ent is not None and ent["key"] == key:
+                return ent["ctx"]
+            if ent is not None:
+                _lib.load().shapemol_destroy(ent["ctx"])
+            extra[slot] = {"ctx": self._new_context(device), "key": key, "bn_eval": False}
+            return extra[slot]["ctx"]
         if self._ctx is not None and key == self._ctx_key:
             return self._ctx
+        self._release(extra=False)
+        self._ctx, self._ctx_key, self._bn_eval_set = self._new_context(device), key, False
+        return self._ctx
+
+    def _new_context(self, device):
         lib = _lib.load()
-        self._release()
         d = self.dims
         cfg = _lib.Config(d.H, d.heads, d.L, d.k, d.G, d.S, d.S_latent, d.temb, d.C, d.T)
         packed = pack_state_dict(self.state_dict(), d.L)
@@ -141,22 +157,33 @@ class ScorePosNet3D(nn.Module):
         mean, var = self._bn_running()
         _lib.check(lib.shapemol_set_bn_running(ctx, mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p), mean.size),
                    "shapemol_set_bn_running")
-        self._ctx, self._ctx_key, self._bn_eval_set = ctx, key, False
+        for name, value in self.__dict__.get("_options", {}).items():       # options set through set_option apply to every context
+            _lib.check(lib.shapemol_set_option(ctx, name.encode(), int(value)), "shapemol_set_option")
         return ctx
 
-    def _sync_bn_mode(self, ctx):
+    def _sync_bn_mode(self, ctx, slot=0):
         """module.eval() / .train() -> the library's batch-norm mode (running statistics / the batch's), as nn.BatchNorm1d
         switches with the module's flag (models/shape_vn_layers.py:45-61).  Sampling in the reference runs in train mode
         (the scripts never call .eval() before sample_diffusion); validate() switches to eval."""
         want = not self.training
+        if slot != 0:
+            ent = self.__dict__["_ctx_extra"][slot]
+            if want != ent["bn_eval"]:
+                _lib.check(_lib.load().shapemol_set_option(ctx, b"bn_eval", int(want)), "shapemol_set_option")
+                ent["bn_eval"] = want
+            return
         if want != getattr(self, "_bn_eval_set", False):
             _lib.check(_lib.load().shapemol_set_option(ctx, b"bn_eval", int(want)), "shapemol_set_option")
             self._bn_eval_set = want
 
-    def _release(self):
+    def _release(self, extra=True):
         if getattr(self, "_ctx", None) is not None:
             _lib.load().shapemol_destroy(self._ctx)
             self._ctx = None
+        if extra:
+            for ent in self.__dict__.get("_ctx_extra", {}).values():
+                _lib.load().shapemol_destroy(ent["ctx"])
+            self.__dict__["_ctx_extra"] = {}
 
     def __del__(self):
         try:
@@ -168,6 +195,14 @@ class ScorePosNet3D(nn.Module):
         """Library tuning / diagnostics knob (see shapemol_set_option)."""
         dev = next(self.parameters()).device
         _lib.check(_lib.load().shapemol_set_option(self._context(dev), name.encode(), int(value)), "shapemol_set_option")
+        if name == "bn_eval":           # keep the cache of _sync_bn_mode truthful
+            self._bn_eval_set = bool(value)
+        else:                           # (the batch-norm mode follows module.training; everything else is remembered for contexts
+            self.__dict__.setdefault("_options", {})[name] = int(value)      #  created later: weight reloads, extra slots)
+        for slot, ent in self.__dict__.get("_ctx_extra", {}).items():
+            _lib.check(_lib.load().shapemol_set_option(ent["ctx"], name.encode(), int(value)), "shapemol_set_option")
+            if name == "bn_eval":
+                ent["bn_eval"] = bool(value)
 
     def debug_read(self, name, shape, dtype):
         out = np.empty(shape, dtype=dtype)
@@ -181,8 +216,6 @@ class ScorePosNet3D(nn.Module):
                 return_all=False):
         """f(x0, v0 | xt, vt): one score evaluation.  Returns the reference's dict
         {'pred_ligand_pos' (N,3), 'pred_ligand_h' (N,H), 'pred_ligand_v' (N,C)}."""
-        if return_all:
-            raise NotImplementedError("return_all=True (per-block outputs) is not part of the accelerated path")
         if time_step is None:
             raise ValueError("time_step is required (time_emb_dim > 0)")
         pos = _check_device_tensor("ligand_pos_perturbed", ligand_pos_perturbed, torch.float32)
@@ -203,9 +236,23 @@ class ScorePosNet3D(nn.Module):
             rc = _lib.load().shapemol_score(ctx, _ptr(pos), _ptr(v), _ptr(batch), n, b, _ptr(shape), _ptr(t),
                                             _ptr(out_pos), _ptr(out_h), _ptr(out_v),
                                             _stream_ptr(torch.cuda.current_stream(dev)))
-        _lib.check(rc, "shapemol_score")
-        self._pending_check = True      # device-side input flags are read at the next check_status()
-        return {"pred_ligand_pos": out_pos, "pred_ligand_h": out_h, "pred_ligand_v": out_v}
+            _lib.check(rc, "shapemol_score")
+            preds = {"pred_ligand_pos": out_pos, "pred_ligand_h": out_h, "pred_ligand_v": out_v}
+            if return_all:
+                # the refine net's all_x / all_h hold its input and the output of each BLOCK (models/uni_transformer.py:489-533;
+                # the shipped schema has num_blocks = 1): [input, final].  The atom-type head on the embedding h0 is one more
+                # evaluation truncated to zero layers (embedding + v-head only).
+                out_v0 = torch.empty_like(out_v)
+                lib = _lib.load()
+                _lib.check(lib.shapemol_set_option(ctx, b"stop_layer", 0), "shapemol_set_option")
+                try:
+                    rc = lib.shapemol_score(ctx, _ptr(pos), _ptr(v), _ptr(batch), n, b, _ptr(shape), _ptr(t), _ptr(torch.empty_like(out_pos)),
+                                            None, _ptr(out_v0), _stream_ptr(torch.cuda.current_stream(dev)))
+                    _lib.check(rc, "shapemol_score")
+                finally:
+                    lib.shapemol_set_option(ctx, b"stop_layer", -1)
+                preds.update(layer_pred_ligand_pos=[pos, out_pos], layer_pred_ligand_v=[out_v0, out_v])
+        return preds
 
     # ------------------------------------------------------------------ validation loss
     def sample_time(self, num_graphs, device):
@@ -293,6 +340,7 @@ class ScorePosNet3D(nn.Module):
         else:
             loss_pos = torch.mean(loss_pos)
         loss_v = torch.mean(kl_v)
+        self.check_status()      # the reference raises from its indexing ops on a bad time step / atom type / batch vector
         return {"loss_pos": loss_pos, "loss_v": loss_v, "loss": loss_pos + loss_v * self.loss_v_weight, "x0": pos,
                 "ligand_pos_perturbed": pos_pert, "ligand_v_perturbed": v_pert, "pred_ligand_pos": pred_pos,
                 "pred_ligand_v": pred_v, "ligand_v_recon": torch.nn.functional.softmax(pred_v, dim=-1)}
@@ -303,7 +351,7 @@ class ScorePosNet3D(nn.Module):
                          threshold_args=None, num_steps=None, center_pos_mode=None, use_grad=False, grad_lr=1,
                          shape_AE=None, use_mesh_data=None, use_pointcloud_data=None, grad_step=500,
                          guide_stren=0, bounds=None, *, noise=None, seed=None, return_traj=True, use_graph=True,
-                         first_step=0, guide_draws=None, _reuse_host_buffers=False):
+                         first_step=0, guide_draws=None, _reuse_host_buffers=False, _slot=0, _async=False):
         """Reverse diffusion chain; same arguments and result dict as the reference.
 
         Extensions (keyword-only): ``noise=(eps, u)`` feeds host-chosen draws, eps (S,N,3) and u (S,N,C)
@@ -315,6 +363,10 @@ class ScorePosNet3D(nn.Module):
         ``use_pointcloud_data=(point_clouds, kdtree, radius)`` with ``grad_step`` is the reference's point-cloud shape
         guidance (``:583-586,699-740``) as a device kernel inside the step (the KD-tree is not used: brute-force float64
         3-nearest search); ``guide_draws`` (S,5,N) float64 feeds the recorded ``np.random.random`` draws (parity mode).
+        Private to shapemol_amd.sampling: ``_slot`` picks one of the model's library contexts (own workspace and captured
+        graphs), ``_async=True`` returns a handle right after the chain has been enqueued; its ``.result()`` waits and
+        builds the dict (chains on different slots then run side by side, and a finished chain's trajectories are
+        unbatched and copied while the next one runs).
         """
         if use_mesh_data is not None or use_grad:
             raise NotImplementedError("mesh / gradient shape guidance is outside the accelerated path")
@@ -333,8 +385,8 @@ class ScorePosNet3D(nn.Module):
         batch = _check_device_tensor("batch_ligand", batch_ligand, torch.int64)
         shape = _check_device_tensor("ligand_shape", ligand_shape, torch.float32).view(-1, self.dims.S, 3)
         n, b, cc, dev = pos.shape[0], shape.shape[0], self.dims.C, pos.device
-        ctx = self._context(dev)
-        self._sync_bn_mode(ctx)
+        ctx = self._context(dev, _slot)
+        self._sync_bn_mode(ctx, _slot)
         lib = _lib.load()
         eps = u = None
         if noise is not None:
@@ -342,15 +394,23 @@ class ScorePosNet3D(nn.Module):
             u = _check_device_tensor("noise[1]", noise[1], torch.float32)
             if tuple(eps.shape) != (num_steps, n, 3) or tuple(u.shape) != (num_steps, n, cc):
                 raise ValueError("noise must be (eps (S,N,3), u (S,N,C))")
+        guided = use_pointcloud_data is not None
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
+            if noise is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            elif guided and guide_draws is None:
+                # host-fed chain noise, device-drawn guidance uniforms: a fresh key per call from numpy's global generator (the
+                # one the reference's guidance draws from, molopt_score_model.py:719), leaving torch's generator -- which the
+                # host_rng mode of the sampling driver replays draw by draw -- untouched
+                seed = int(np.random.randint(0, 2 ** 62, dtype=np.int64))
+            else:
+                seed = 0
         # the largest molecule of the batch lets the library fold the per-layer coordinate update into the next attention
         # kernel (one tiny synchronising reduction per chain; the reference synchronises at every step)
         _lib.check(lib.shapemol_set_option(ctx, b"max_mol_atoms", int(torch.bincount(batch).max().item()) if n else 0), "shapemol_set_option")
-        guided = use_pointcloud_data is not None
+        gd = None
         if guided:
             cloud = np.ascontiguousarray(np.asarray(use_pointcloud_data[0], dtype=np.float64).reshape(-1, 3))
-            gd = None
             if guide_draws is not None:
                 gd = _check_device_tensor("guide_draws", guide_draws, torch.float64)
                 if tuple(gd.shape) != (num_steps, 5, n):
@@ -368,74 +428,33 @@ class ScorePosNet3D(nn.Module):
                 setattr(tr, name, bufs[name].data_ptr())
         out_pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
         out_v = torch.empty((n,), dtype=torch.int64, device=dev)
-        with torch.cuda.device(dev):
-            cur = torch.cuda.current_stream(dev)
-            # hipGraph capture is not allowed on the legacy default stream: run the chain on a side stream
-            side = self._side_stream(dev)
-            side.wait_stream(cur)
-            if first_step:
-                _lib.check(lib.shapemol_set_option(ctx, b"first_step", int(first_step)), "shapemol_set_option")
-            rc = lib.shapemol_sample(ctx, _ptr(pos), _ptr(v), _ptr(batch), n, b, _ptr(shape), int(num_steps),
-                                     _ptr(eps), _ptr(u), C.c_uint64(seed), C.byref(tr), _ptr(out_pos), _ptr(out_v),
-                                     1 if use_graph else 0, _stream_ptr(side))
-            if first_step:
-                lib.shapemol_set_option(ctx, b"first_step", 0)
-            cur.wait_stream(side)
-        _lib.check(rc, "shapemol_sample")
-        if guided:
-            torch.cuda.synchronize(dev)
-            _lib.check(lib.shapemol_set_guidance(ctx, None, 0, 0.0, 0, None), "shapemol_set_guidance")
-        cur.synchronize()               # the reference returns finished results; also the point where input flags are read
-        self.check_status()
-        for t_ in (pos, v, batch, shape, eps, u, out_pos, out_v, *bufs.values()):
-            if t_ is not None:
-                t_.record_stream(side)
-        res = {"pos": out_pos, "v": out_v, "pos_uncond_traj": [], "v_uncond_traj": []}
-        if return_traj and _reuse_host_buffers == "device":
-            # private to shapemol_amd.sampling: hand out the (S, N, ...) device buffers; the driver reorders them on the
-            # device and copies each to the host once
-            res.update(pos_traj=[], v_traj=[], v0_traj=[], vt_traj=[], pos_cond_traj=[], v_cond_traj=[])
-            res["_stacked"] = dict(bufs)
-        elif return_traj:
-            # one D2H copy per trajectory, through pinned staging buffers (the reference copies step by step, :671-681)
-            # (_reuse_host_buffers: private to shapemol_amd.sampling, which consumes the host tensors before the next call)
-            host = {k: self._to_host(bufs[k], k if _reuse_host_buffers else None) for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj")}
-            res.update(pos_traj=list(host["pos_traj"].unbind(0)), v_traj=list(host["v_traj"].unbind(0)),
-                       v0_traj=list(host["v0_traj"].unbind(0)), vt_traj=list(host["vt_traj"].unbind(0)),
-                       pos_cond_traj=list(bufs["pos_cond_traj"].unbind(0)), v_cond_traj=list(bufs["v_cond_traj"].unbind(0)))
-            # not a key of the reference: the same trajectories as whole (S, N, ...) tensors, for callers that unbatch
-            # them at once (shapemol_amd.sampling) instead of re-stacking the per-step lists
-            res["_stacked"] = dict(host, pos_cond_traj=bufs["pos_cond_traj"], v_cond_traj=bufs["v_cond_traj"])
-        else:
-            res.update(pos_traj=[], v_traj=[], v0_traj=[], vt_traj=[], pos_cond_traj=[], v_cond_traj=[])
-        return res
+        pending = _PendingChain(self, ctx, dev, guided, bufs, out_pos, out_v, return_traj, _reuse_host_buffers,
+                                keep=(pos, v, batch, shape, eps, u, gd))
+        try:
+            with torch.cuda.device(dev):
+                cur = torch.cuda.current_stream(dev)
+                # hipGraph capture is not allowed on the legacy default stream: run the chain on a side stream
+                side = self._side_stream(dev, _slot)
+                side.wait_stream(cur)
+                if first_step:
+                    _lib.check(lib.shapemol_set_option(ctx, b"first_step", int(first_step)), "shapemol_set_option")
+                try:
+                    rc = lib.shapemol_sample(ctx, _ptr(pos), _ptr(v), _ptr(batch), n, b, _ptr(shape), int(num_steps),
+                                             _ptr(eps), _ptr(u), C.c_uint64(seed), C.byref(tr), _ptr(out_pos), _ptr(out_v),
+                                             1 if use_graph else 0, _stream_ptr(side))
+                finally:
+                    if first_step:
+                        lib.shapemol_set_option(ctx, b"first_step", 0)
+                pending.side, pending.cur = side, cur
+            _lib.check(rc, "shapemol_sample")
+        except BaseException:
+            pending.abandon()
+            raise
+        return pending if _async else pending.result()
 
     def pointcloud_shape_guidance(self, use_pointcloud_data, pred_ligand_pos, k=3, ratio=0.2, *, draws=None, seed=None):
-        """``pointcloud_shape_guidance`` of the reference (``models/molopt_score_model.py:699-740``) as one device kernel:
-        guides ``pred_ligand_pos`` (N,3) in place and returns it.  ``use_pointcloud_data = (point_clouds, kdtree, radius)``
-        as there (the KD-tree is not used).  ``draws`` (5,N) float64 device tensor: the uniform of every
-        (iteration, atom) (parity mode); otherwise device Philox keyed by ``seed``."""
-        if k != 3 or ratio != 0.2:
-            raise NotImplementedError("the device kernel implements the reference's defaults k=3, ratio=0.2")
-        pos = _check_device_tensor("pred_ligand_pos", pred_ligand_pos, torch.float32)
-        if pos.data_ptr() != pred_ligand_pos.data_ptr():
-            raise ValueError("pred_ligand_pos must be contiguous (it is updated in place)")
-        dev = pos.device
-        ctx, lib = self._context(dev), _lib.load()
-        cloud = np.ascontiguousarray(np.asarray(use_pointcloud_data[0], dtype=np.float64).reshape(-1, 3))
-        gd = None if draws is None else _check_device_tensor("draws", draws, torch.float64)
-        if gd is not None and tuple(gd.shape) != (5, pos.shape[0]):
-            raise ValueError("draws must be (5, N) float64")
-        if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if gd is None else 0
-        _lib.check(lib.shapemol_set_guidance(ctx, cloud.ctypes.data_as(C.c_void_p), cloud.shape[0], float(use_pointcloud_data[2]), 0, None),
-                   "shapemol_set_guidance")
-        with torch.cuda.device(dev):
-            rc = lib.shapemol_guide_points(ctx, _ptr(pos), pos.shape[0], _ptr(gd), C.c_uint64(seed), _stream_ptr(torch.cuda.current_stream(dev)))
-        _lib.check(rc, "shapemol_guide_points")
-        torch.cuda.synchronize(dev)
-        _lib.check(lib.shapemol_set_guidance(ctx, None, 0, 0.0, 0, None), "shapemol_set_guidance")
-        return pred_ligand_pos
+        """Method form of the module-level :func:`pointcloud_shape_guidance` (kept for callers that hold a model)."""
+        return pointcloud_shape_guidance(use_pointcloud_data, pred_ligand_pos, k=k, ratio=ratio, draws=draws, seed=seed)
 
     def check_status(self):
         """Synchronise and raise if the last forward / sample_diffusion saw an invalid input (batch vector not sorted
@@ -460,12 +479,98 @@ class ScorePosNet3D(nn.Module):
         torch.cuda.current_stream(t.device).synchronize()
         return h
 
-    def _side_stream(self, dev):
-        s = getattr(self, "_stream", None)
+    def _side_stream(self, dev, slot=0):
+        streams = self.__dict__.setdefault("_streams", {})
+        s = streams.get(slot)
         if s is None or s.device != dev:
             s = torch.cuda.Stream(device=dev)
-            self._stream = s
+            streams[slot] = s
         return s
+
+
+class _PendingChain:
+    """A reverse chain that has been enqueued on its context's side stream (ScorePosNet3D.sample_diffusion(_async=True));
+    result() waits for it, reads the status flags and builds the reference's result dict."""
+
+    def __init__(self, model, ctx, dev, guided, bufs, out_pos, out_v, return_traj, reuse, keep):
+        self.model, self.ctx, self.dev, self.guided, self.bufs = model, ctx, dev, guided, bufs
+        self.out_pos, self.out_v, self.return_traj, self.reuse, self.keep = out_pos, out_v, return_traj, reuse, keep
+        self.side = self.cur = None
+        self.done = False
+
+    def _drop_guidance(self):
+        if self.guided:      # whatever happened, the context must not keep the cloud (and the caller-owned draws pointer) installed
+            self.guided = False
+            torch.cuda.synchronize(self.dev)
+            _lib.check(_lib.load().shapemol_set_guidance(self.ctx, None, 0, 0.0, 0, None), "shapemol_set_guidance")
+
+    def abandon(self):
+        self.done = True
+        self._drop_guidance()
+
+    def result(self):
+        assert not self.done, "result() of a chain can be taken once"
+        self.done = True
+        try:
+            # the reference returns finished results; also the point where the input flags are read (only this chain's stream
+            # is waited for: another slot's chain may be running beside it)
+            _lib.check(_lib.load().shapemol_status_stream(self.ctx, None, _stream_ptr(self.side)), "input check")
+        finally:
+            self._drop_guidance()
+        self.cur.wait_stream(self.side)
+        m, bufs = self.model, self.bufs
+        for t_ in (*self.keep, self.out_pos, self.out_v, *bufs.values()):
+            if t_ is not None:
+                t_.record_stream(self.side)
+        res = {"pos": self.out_pos, "v": self.out_v, "pos_uncond_traj": [], "v_uncond_traj": []}
+        if self.return_traj and self.reuse == "device":
+            # private to shapemol_amd.sampling: hand out the (S, N, ...) device buffers; the driver reorders them on the
+            # device and copies each to the host once
+            res.update(pos_traj=[], v_traj=[], v0_traj=[], vt_traj=[], pos_cond_traj=[], v_cond_traj=[])
+            res["_stacked"] = dict(bufs)
+        elif self.return_traj:
+            # one D2H copy per trajectory, through pinned staging buffers (the reference copies step by step, :671-681)
+            # (_reuse_host_buffers: private to shapemol_amd.sampling, which consumes the host tensors before the next call)
+            host = {k: m._to_host(bufs[k], k if self.reuse else None) for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj")}
+            res.update(pos_traj=list(host["pos_traj"].unbind(0)), v_traj=list(host["v_traj"].unbind(0)),
+                       v0_traj=list(host["v0_traj"].unbind(0)), vt_traj=list(host["vt_traj"].unbind(0)),
+                       pos_cond_traj=list(bufs["pos_cond_traj"].unbind(0)), v_cond_traj=list(bufs["v_cond_traj"].unbind(0)))
+            # not a key of the reference: the same trajectories as whole (S, N, ...) tensors, for callers that unbatch
+            # them at once (shapemol_amd.sampling) instead of re-stacking the per-step lists
+            res["_stacked"] = dict(host, pos_cond_traj=bufs["pos_cond_traj"], v_cond_traj=bufs["v_cond_traj"])
+        else:
+            res.update(pos_traj=[], v_traj=[], v0_traj=[], vt_traj=[], pos_cond_traj=[], v_cond_traj=[])
+        return res
+
+
+def pointcloud_shape_guidance(use_pointcloud_data, pred_ligand_pos, k=3, ratio=0.2, *, draws=None, seed=None):
+    """``pointcloud_shape_guidance`` of the reference (module level there too, ``models/molopt_score_model.py:699-740``) as
+    one device kernel: atoms of ``pred_ligand_pos`` (N,3) whose ``k`` = 3 nearest cloud points are on average farther than
+    ``radius`` are pulled towards their mean by ``u * (0.8 - ratio) + ratio``, up to five times; the tensor is updated in
+    place and returned.  ``use_pointcloud_data = (point_clouds, kdtree, radius)`` as there (the KD-tree is not used:
+    brute-force float64 search on the device).
+    Extensions (keyword-only): ``draws`` (5,N) float64 device tensor = the uniform of every (iteration, atom) (parity
+    mode); otherwise device Philox keyed by ``seed`` (default: drawn from numpy's global generator, which the reference's
+    function draws its uniforms from)."""
+    if k != 3:
+        raise NotImplementedError("the device kernel searches the reference's default k = 3 nearest cloud points")
+    pos = _check_device_tensor("pred_ligand_pos", pred_ligand_pos, torch.float32)
+    if pos.data_ptr() != pred_ligand_pos.data_ptr() or pos.dim() != 2 or pos.shape[1] != 3:
+        raise ValueError("pred_ligand_pos must be a contiguous (N, 3) tensor (it is updated in place)")
+    cloud = np.ascontiguousarray(np.asarray(use_pointcloud_data[0], dtype=np.float64).reshape(-1, 3))
+    gd = None if draws is None else _check_device_tensor("draws", draws, torch.float64)
+    if gd is not None and tuple(gd.shape) != (5, pos.shape[0]):
+        raise ValueError("draws must be (5, N) float64")
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 62, dtype=np.int64)) if gd is None else 0
+    if pos.shape[0] == 0:
+        return pred_ligand_pos
+    with torch.cuda.device(pos.device):
+        rc = _lib.load().shapemol_pointcloud_guidance(cloud.ctypes.data_as(C.c_void_p), cloud.shape[0], float(use_pointcloud_data[2]),
+                                                      float(ratio), _ptr(pos), pos.shape[0], _ptr(gd), C.c_uint64(seed),
+                                                      _stream_ptr(torch.cuda.current_stream(pos.device)))
+    _lib.check(rc, "shapemol_pointcloud_guidance")
+    return pred_ligand_pos
 
 
 def log_sample_categorical(logits, *, u=None, seed=None):

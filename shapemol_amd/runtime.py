@@ -5,6 +5,7 @@ A serving loop that samples batch after batch wants the opposite: buffers alloca
 captured hipGraph of one chain step reused, no host work in the loop.  ``ChainRunner`` is that.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -37,8 +38,14 @@ class ChainRunner:
         self.stream = torch.cuda.Stream(device=self.dev)
         self.ctx = model._context(self.dev)
         _lib.check(_lib.load().shapemol_reserve(self.ctx, self.n, self.b), "shapemol_reserve")
-        # a library context owns ONE workspace: chains of the same model must not be in flight on two streams at once
-        model.__dict__.setdefault("_runners", []).append(self)
+        # a library context owns ONE workspace: chains of the same model must not be in flight on two streams at once.  The
+        # registry holds weak references: a runner's buffers (GBs at B = 1024 with trajectories) go when the runner goes
+        model.__dict__.setdefault("_runners", weakref.WeakSet()).add(self)
+
+    def close(self):
+        """Wait for the runner's chain and leave the model's registry (its buffers are freed with the last reference)."""
+        self.stream.synchronize()
+        self.model.__dict__.get("_runners", set()).discard(self)
 
     def load_batch(self, init_pos, init_v, batch, shape):
         self.pos0.copy_(torch.as_tensor(init_pos)); self.v0.copy_(torch.as_tensor(init_v))
@@ -54,11 +61,12 @@ class ChainRunner:
     def run(self, num_steps, seed=0, use_graph=True):
         """Enqueue a chain of `num_steps` reverse steps on the runner's stream (no host sync)."""
         assert 1 <= num_steps <= self.max_steps
-        for other in self.model.__dict__.get("_runners", []):
+        for other in list(self.model.__dict__.get("_runners", ())):
             if other is not self and not other.stream.query():
                 raise RuntimeError("another ChainRunner of the same model still has a chain in flight: a context has one workspace; "
                                    "synchronize() it first, or give the second runner its own model (own context)")
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
+        self.model._sync_bn_mode(self.ctx)      # module.eval() / .train() since the last call (shared context)
         with torch.cuda.device(self.dev):
             rc = _lib.load().shapemol_sample(self.ctx, p(self.pos0), p(self.v0), p(self.batch), self.n, self.b, p(self.shape),
                                              int(num_steps), p(self.eps), p(self.u), C.c_uint64(seed), C.byref(self.traj),

@@ -13,6 +13,7 @@ The unbatching is the part worth doing differently on a GPU: the reference copie
 host step by step (4-6 D2H copies per reverse step); here each trajectory crosses PCIe once, as one array, and is
 split on the host.
 """
+import collections
 import time
 from functools import partial
 
@@ -51,23 +52,32 @@ def unbatch(stacked, cum_atoms, dtype=None):
     return [np.ascontiguousarray(arr[:, cum_atoms[k]:cum_atoms[k + 1]]) for k in range(len(cum_atoms) - 1)]
 
 
-def _unbatch_on_device(t, counts, dtype=None):
+def _regroup_index(S, counts, dev):
+    """Destination row of every (step, atom) row of an (S, N, ...) trajectory when the rows are regrouped molecule by molecule
+    ((S, n_0, ...) block, then (S, n_1, ...), ...): (S * N,) int64 on the device.  Computed once per batch, used by all six."""
+    cnt = torch.as_tensor(counts, dtype=torch.int64, device=dev)
+    N = int(cnt.sum())
+    cum = torch.cumsum(cnt, 0) - cnt                                   # first atom of each molecule
+    mol = torch.repeat_interleave(torch.arange(len(counts), device=dev), cnt)
+    local = torch.arange(N, device=dev) - cum[mol]
+    dest = (cum[mol] * S + local).unsqueeze(0) + torch.arange(S, device=dev).unsqueeze(1) * cnt[mol].unsqueeze(0)   # (S, N)
+    return dest.reshape(-1)
+
+
+def _unbatch_on_device(t, counts, dtype=None, dest=None):
     """(S, N, ...) DEVICE tensor -> list of per-molecule host arrays (S, n_i, ...): rows are regrouped molecule by
     molecule on the device (one index_copy), cross PCIe once into pinned memory, and the per-molecule arrays are
     contiguous views of that one host array (no per-molecule copies)."""
     S, N = t.shape[0], t.shape[1]
     tail = tuple(t.shape[2:])
     dev = t.device
-    cnt = torch.as_tensor(counts, dtype=torch.int64, device=dev)
-    cum = torch.cumsum(cnt, 0) - cnt                                   # first atom of each molecule
-    mol = torch.repeat_interleave(torch.arange(len(counts), device=dev), cnt)
-    local = torch.arange(N, device=dev) - cum[mol]
-    dest = (cum[mol] * S + local).unsqueeze(0) + torch.arange(S, device=dev).unsqueeze(1) * cnt[mol].unsqueeze(0)   # (S, N)
+    if dest is None:
+        dest = _regroup_index(S, counts, dev)
     src = t.reshape(S * N, -1)
     if dtype is not None:
         src = src.to(dtype)
     out = torch.empty_like(src)
-    out.index_copy_(0, dest.reshape(-1), src)
+    out.index_copy_(0, dest, src)
     try:
         host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
         host.copy_(out, non_blocking=True)
@@ -94,7 +104,7 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
                             pos_only=False, center_pos_mode="none", sample_func=None, threshold_type=None,
                             threshold_args=None, sample_num_atoms="prior", bounds=None, ref_num_atoms=None,
                             ref_atom_feature=None, guide_stren=0, seed=None, use_graph=True, host_rng=False,
-                            use_pointcloud_data=None, grad_step=1000):
+                            use_pointcloud_data=None, grad_step=1000, pipeline=2):
     """``sample_diffusion_ligand`` of the reference for one shape condition.
 
     shape_emb        (32, 3) latent of the condition (``data.shape_emb``); repeated per molecule of a batch.
@@ -113,6 +123,13 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
                      (``config.sample.use_pointcloud*`` / ``grad_step``, ``scripts/sample_diffusion.py:237-243``): the point-cloud
                      shape guidance runs as a device kernel inside every step with t > grad_step.
     shape_emb        may also be (n_data, 32, 3), one condition per molecule of a single batch (fixtures).
+    pipeline         batches in flight on the device (accelerated model only; 1 = one after the other, as the reference).  With 2
+                     (default) two library contexts alternate: while the chain of batch i runs, the trajectories of batch i - 1
+                     are regrouped, copied to the host and unbatched, and batch i + 1 is prepared, captured and enqueued beside
+                     it -- the device never waits for the host.  Batches are independent (own batch-norm statistics, own
+                     noise), the random draws are made in batch order, and results are returned in batch order, so the output
+                     does not depend on this value.  ``time_list`` then holds each batch's wall time from its enqueue to its
+                     delivery, which overlaps its neighbours'.
 
     Returns the reference's 9-tuple: ``(pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj,
     time_list, pred_pos_cond_traj, pred_v_cond_traj)``; positions are float64 host arrays, as there.
@@ -130,6 +147,39 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
     all_pred_v0_traj, all_pred_vt_traj = [], []
     time_list = []
     num_batch = int(np.ceil(num_samples / batch_size))
+    accelerated = getattr(model, "_accelerated", False)
+    depth = max(1, int(pipeline)) if accelerated else 1
+    if accelerated and depth > 1 and use_pointcloud_data is not None:
+        depth = 1          # installing / removing the guidance cloud drains the device: nothing to overlap
+    pending = collections.deque()
+
+    def deliver(job):
+        """Wait for a batch's chain, unbatch its final state and trajectories into per-molecule host arrays."""
+        nonlocal all_pred_pos, all_pred_v, all_pred_pos_traj, all_pred_v_traj, all_pred_pos_cond_traj, all_pred_v_cond_traj
+        nonlocal all_pred_v0_traj, all_pred_vt_traj
+        handle, ligand_num_atoms, n_data, t1 = job
+        r = handle.result() if hasattr(handle, "result") else handle
+        cum = np.cumsum([0] + ligand_num_atoms)
+        pos = r["pos"].cpu().numpy().astype(np.float64)
+        all_pred_pos += [pos[cum[k]:cum[k + 1]] for k in range(n_data)]
+        v = r["v"].cpu().numpy()
+        all_pred_v += [v[cum[k]:cum[k + 1]] for k in range(n_data)]
+        st = r.get("_stacked")
+        if st is not None and all(torch.is_tensor(x) and x.is_cuda for x in st.values()):
+            some = next(iter(st.values()))
+            dest = _regroup_index(some.shape[0], ligand_num_atoms, some.device)
+            take = lambda name, dt=None: _unbatch_on_device(st[name], ligand_num_atoms, dt, dest)      # noqa: E731
+        else:
+            take = lambda name, dt=None: unbatch(_traj_to_host(r, name), cum, None if dt is None else np.float64)  # noqa: E731
+        all_pred_pos_traj += take("pos_traj", torch.float64)
+        all_pred_pos_cond_traj += take("pos_cond_traj", torch.float64)
+        all_pred_v_traj += take("v_traj")
+        all_pred_v_cond_traj += take("v_cond_traj")
+        if not pos_only:
+            all_pred_v0_traj += take("v0_traj")
+            all_pred_vt_traj += take("vt_traj")
+        time_list.append(time.time() - t1)
+
     for i in range(num_batch):
         n_data = batch_size if i < num_batch - 1 else num_samples - batch_size * (num_batch - 1)
         t1 = time.time()
@@ -158,7 +208,7 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
                 init_ligand_v = log_sample_categorical(uniform_logits)
         noise_kw = {}
         if host_rng:
-            if not getattr(model, "_accelerated", False):
+            if not accelerated:
                 raise ValueError("host_rng feeds recorded draws to the device chain: it needs the accelerated model")
             n_steps = num_steps if num_steps is not None else model.num_timesteps
             eps = torch.empty(n_steps, all_ligand_atoms, 3)
@@ -167,32 +217,19 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
                 eps[s_] = torch.randn(all_ligand_atoms, 3)
                 uu[s_] = torch.rand(all_ligand_atoms, model.num_classes)
             noise_kw["noise"] = (eps.to(dev), uu.to(dev))
-        r = model.sample_diffusion(
+        while len(pending) >= depth:                     # the slot this batch will use must be free again
+            deliver(pending.popleft())
+        handle = model.sample_diffusion(
             init_ligand_pos=init_ligand_pos, init_ligand_v=init_ligand_v, batch_ligand=batch_ligand,
             ligand_shape=(shape_emb if per_mol_shapes else shape_emb.repeat(n_data, 1, 1)).to(dev).reshape(n_data, -1),
             threshold_type=threshold_type, threshold_args=threshold_args, num_steps=num_steps,
             center_pos_mode=center_pos_mode, guide_stren=guide_stren, bounds=bounds,
             use_pointcloud_data=use_pointcloud_data, grad_step=grad_step,
             seed=None if seed is None else int(seed) + i, use_graph=use_graph, **noise_kw,
-            **({"_reuse_host_buffers": "device"} if getattr(model, "_accelerated", False) else {}))
-        cum = np.cumsum([0] + ligand_num_atoms)
-        pos = r["pos"].cpu().numpy().astype(np.float64)
-        all_pred_pos += [pos[cum[k]:cum[k + 1]] for k in range(n_data)]
-        v = r["v"].cpu().numpy()
-        all_pred_v += [v[cum[k]:cum[k + 1]] for k in range(n_data)]
-        st = r.get("_stacked")
-        if st is not None and all(torch.is_tensor(x) and x.is_cuda for x in st.values()):
-            take = lambda name, dt=None: _unbatch_on_device(st[name], ligand_num_atoms, dt)      # noqa: E731
-        else:
-            take = lambda name, dt=None: unbatch(_traj_to_host(r, name), cum, None if dt is None else np.float64)  # noqa: E731
-        all_pred_pos_traj += take("pos_traj", torch.float64)
-        all_pred_pos_cond_traj += take("pos_cond_traj", torch.float64)
-        all_pred_v_traj += take("v_traj")
-        all_pred_v_cond_traj += take("v_cond_traj")
-        if not pos_only:
-            all_pred_v0_traj += take("v0_traj")
-            all_pred_vt_traj += take("vt_traj")
-        time_list.append(time.time() - t1)
+            **({"_reuse_host_buffers": "device", "_slot": i % depth, "_async": True} if accelerated else {}))
+        pending.append((handle, ligand_num_atoms, n_data, t1))
+    while pending:
+        deliver(pending.popleft())
     return (all_pred_pos, all_pred_v, all_pred_pos_traj, all_pred_v_traj, all_pred_v0_traj, all_pred_vt_traj, time_list,
             all_pred_pos_cond_traj, all_pred_v_cond_traj)
 

@@ -12,6 +12,9 @@ because these take tens of CPU-minutes while make_golden.py's set regenerates in
     python tests/golden/make_golden_r2.py se        # frozen shape encoder (VN_DGCNN_Encoder), 3 clouds of 512 points
     python tests/golden/make_golden_r2.py loss      # get_diffusion_loss as validate() calls it, module in eval and in train mode
     python tests/golden/make_golden_r2.py all
+    python tests/golden/make_golden_r2.py retall        # round 3: forward(return_all=True)
+    python tests/golden/make_golden_r2.py b256_tail     # round 3: the last 49 steps of the b256 chain in 10-step snapshots (minutes)
+    python tests/golden/make_golden_r2.py b1024_s1000   # round 3: configs[2]/[3] per-GPU batch at full length (~3 CPU-hours)
 
 Noise is the hash noise of synth.step_noise (a pure function of (seed, step)), so the fixtures
 hold only the states: end pos / v, snapshots, and the first steps (so that the CPU suite can
@@ -35,7 +38,9 @@ from shapemol_amd import synth  # noqa: E402
 t_ = G.t_
 
 
-def chain(model, tag, B, S, seed, every, head, atoms_range=None, max_atoms=None):
+def chain(model, tag, B, S, seed, every, head, atoms_range=None, max_atoms=None, tail=None):
+    """tail=(first, every): also keep the states after reverse steps first, first + every, ... (finer windows at the end of a
+    full-length chain, where the posterior passes the network's x0 estimate through almost unchanged)."""
     bb = synth.synthetic_batch(B, seed=seed, atoms_range=atoms_range, max_atoms=max_atoms)
     n = len(bb["batch"])
     eps, u = zip(*[synth.step_noise(n, 15, s, seed=seed) for s in range(S)])
@@ -43,18 +48,54 @@ def chain(model, tag, B, S, seed, every, head, atoms_range=None, max_atoms=None)
     with G.fed_noise(list(eps), list(u)), contextlib.redirect_stdout(open(os.devnull, "w")):
         r = model.sample_diffusion(t_(bb["init_pos"]), t_(bb["init_v"]), t_(bb["batch"]),
                                    t_(bb["shape"]).view(B, -1), num_steps=S, center_pos_mode="none")
+    del eps, u
     pos_traj = torch.stack(r["pos_traj"]).numpy()
     v_traj = torch.stack(r["v_traj"]).numpy()
-    logp = torch.stack(r["vt_traj"]).numpy()
-    top2 = np.sort(logp, -1)[..., -2:]
+    extra = {}
+    if tail is not None:
+        extra = dict(tail_first=tail[0], tail_every=tail[1], pos_traj_tail=pos_traj[tail[0]::tail[1]],
+                     v_traj_tail=v_traj[tail[0]::tail[1]].astype(np.int8))
     np.savez_compressed(
         os.path.join(HERE, f"chain_{tag}_hash.npz"), B=B, S=S, seed=seed, every=every, head=head,
         counts=bb["counts"], pos=r["pos"].numpy(), v=r["v"].numpy(),
         pos_traj_sub=pos_traj[::every], v_traj_sub=v_traj[::every].astype(np.int8),
         pos_traj_head=pos_traj[:head], v_traj_head=v_traj[:head].astype(np.int8),
         pos0_first=r["pos_cond_traj"][0].numpy(), v0_first=r["v0_traj"][0].numpy(),
-        vt_last=r["vt_traj"][-1].numpy())
+        vt_last=r["vt_traj"][-1].numpy(), **extra)
     print(f"chain {tag}: N = {n}, {S} steps in {time.time() - t0:.0f} s", flush=True)
+
+
+def chain_tail(model, src_tag, tag, max_atoms=None, every=10):
+    """The last window of a committed full-length chain in finer snapshots WITHOUT re-running the whole chain: the reference's
+    loop runs t = num_timesteps - 1 ... num_timesteps - num_steps (models/molopt_score_model.py:558) and indexes every
+    schedule table and the time embedding by t itself, so with ``model.num_timesteps`` lowered to the number of steps
+    left it runs exactly the chain's last steps from the committed state.  Self-check: the end state must reproduce the
+    full chain's end state bit for bit."""
+    c = np.load(os.path.join(HERE, f"chain_{src_tag}_hash.npz"))
+    B, S, seed, ev = int(c["B"]), int(c["S"]), int(c["seed"]), int(c["every"])
+    bb = synth.synthetic_batch(B, seed=seed, max_atoms=max_atoms)
+    n = len(bb["batch"])
+    j = len(c["pos_traj_sub"]) - 1
+    done = j * ev + 1                                   # reverse steps 0 .. j * ev are behind the last snapshot
+    left = S - done
+    eps, u = zip(*[synth.step_noise(n, 15, s, seed=seed) for s in range(done, S)])
+    T_full = model.num_timesteps
+    model.num_timesteps = left
+    try:
+        with G.fed_noise(list(eps), list(u)), contextlib.redirect_stdout(open(os.devnull, "w")):
+            r = model.sample_diffusion(t_(c["pos_traj_sub"][j]), t_(c["v_traj_sub"][j].astype(np.int64)), t_(bb["batch"]),
+                                       t_(bb["shape"]).view(B, -1), num_steps=left, center_pos_mode="none")
+    finally:
+        model.num_timesteps = T_full
+    same = np.array_equal(r["pos"].numpy(), c["pos"]) and np.array_equal(r["v"].numpy(), c["v"])
+    print(f"chain_tail {tag}: steps {done}..{S - 1}; end state reproduces the full chain bit for bit: {same}", flush=True)
+    assert same, "the resumed tail must reproduce the committed end state (same BLAS thread count as the full chain?)"
+    pos_traj = torch.stack(r["pos_traj"]).numpy()
+    v_traj = torch.stack(r["v_traj"]).numpy()
+    # state after reverse step done + i is pos_traj[i]; keep the steps that are multiples of `every`
+    first = (-done) % every
+    np.savez_compressed(os.path.join(HERE, f"chain_{tag}_hash.npz"), src=src_tag, first_step=done + first, every=every,
+                        pos_traj_tail=pos_traj[first::every], v_traj_tail=v_traj[first::every].astype(np.int8))
 
 
 class GuideRecorder:
@@ -206,13 +247,19 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     # float32 reductions of the CPU BLAS depend on the thread count: every fixture records the count it was made with
     # (the 47-minute B=256 chain ran on 6 threads beside a build, the k=32 set on 3), and a regeneration uses the same
-    threads = {"b256": 6, "b1024": 8, "k32": 3, "guide": 8, "se": 8, "loss": 8}
+    threads = {"b256": 6, "b1024": 8, "k32": 3, "guide": 8, "se": 8, "loss": 8, "b256_tail": 6, "b1024_s1000": 5, "b512_k32": 6, "grad": 8}
     def use_threads(task):
         torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", threads[task])))
     torch.set_num_threads(8)
-    if what in ("b256", "b1024", "all"):
+    if what in ("b256", "b1024", "b256_tail", "b1024_s1000", "all"):
         model, _ = G.load_reference_model()
         G.synthetic_load(model, seed=7)
+        if what == "b256_tail":          # (not part of "all": derived from the committed b256 chain, minutes)
+            use_threads("b256_tail")
+            chain_tail(model, "b256_s1000", "b256_s1000_tail", max_atoms=38)
+        if what == "b1024_s1000":        # (not part of "all": ~3 CPU-hours) configs[2]/[3] at full length
+            use_threads("b1024_s1000")
+            chain(model, "b1024_s1000", 1024, 1000, 15, every=50, head=2, max_atoms=38, tail=(960, 10))
         if what in ("b1024", "all"):
             use_threads("b1024")
             chain(model, "b1024_s50", 1024, 50, 14, every=10, head=2, max_atoms=38)
@@ -222,6 +269,18 @@ def main():
     if what in ("loss", "all"):
         use_threads("loss")
         loss_fixture()
+    if what in ("retall", "all"):        # round 3: forward(..., return_all=True) on the inputs of forward_b4.npz (molopt_score_model.py:312-319)
+        torch.set_num_threads(8)
+        model, _ = G.load_reference_model()
+        G.synthetic_load(model, seed=7)
+        f = np.load(os.path.join(HERE, "forward_b4.npz"))
+        with torch.no_grad():
+            out = model(t_(f["pos"]), t_(f["v"]), t_(f["batch"]), t_(f["shape"]), time_step=t_(f["tmix_t"]), return_all=True)
+        assert np.array_equal(out["pred_ligand_pos"].numpy(), f["tmix_pred_ligand_pos"])        # same evaluation as the committed fixture
+        np.savez_compressed(os.path.join(HERE, "forward_b4_return_all.npz"), n_layer_entries=len(out["layer_pred_ligand_pos"]),
+                            **{f"layer_pos_{i}": x.numpy() for i, x in enumerate(out["layer_pred_ligand_pos"])},
+                            **{f"layer_v_{i}": x.numpy() for i, x in enumerate(out["layer_pred_ligand_v"])})
+        print("return_all:", len(out["layer_pred_ligand_pos"]), "entries", flush=True)
     if what in ("se", "all"):
         use_threads("se")
         G.install_stand_ins()

@@ -79,3 +79,29 @@ def test_gather_is_identity_without_process_group():
     pos, v, c = torch.zeros(5, 3), torch.zeros(5, dtype=torch.long), torch.tensor([2, 3])
     p2, v2, c2 = gather_molecules(pos, v, c)
     assert p2 is pos and v2 is v and c2 is c
+
+
+def _single_rank_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        pos, v, counts = (torch.from_numpy(a) for a in _rank_batch(0, -1))
+        p0, v0, c0 = gather_molecules(pos, v, counts)                               # shortcut: the same objects
+        p1, v1, c1 = gather_molecules(pos, v, counts, _single_rank_too=True)        # the packed collective path
+        q.put((p0 is pos, torch.equal(p1, pos) and torch.equal(v1, v) and torch.equal(c1, counts) and p1 is not pos,
+               str(p1.dtype), str(v1.dtype), str(c1.dtype)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_single_rank_forced_through_the_collective():
+    """A 1-rank group pushed through packing / all_gather_into_tensor / unpacking (what tests/test_gpu_parity.py does with the
+    nccl backend on one MI355X, and `bench.py --force-collective`)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    shortcut, same, dp, dv, dc = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert shortcut and same and (dp, dv, dc) == ("torch.float32", "torch.int64", "torch.int64")

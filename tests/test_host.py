@@ -123,6 +123,44 @@ def test_no_cpu_fallback():
         shapemol_amd.log_sample_categorical(z(3, 15))
 
 
+def test_star_import_exposes_the_reference_module_surface():
+    """`from models.molopt_score_model import *` users: every name of __all__ exists, and the module-level functions have
+    the reference's positional signatures (models/molopt_score_model.py:98,699)."""
+    import inspect
+    import shapemol_amd.molopt_score_model as M
+    ns = {}
+    exec("from shapemol_amd.molopt_score_model import *", ns)
+    for name in M.__all__:
+        assert name in ns, name
+    sig = inspect.signature(M.pointcloud_shape_guidance)
+    assert list(sig.parameters)[:4] == ["use_pointcloud_data", "pred_ligand_pos", "k", "ratio"]
+    assert sig.parameters["k"].default == 3 and sig.parameters["ratio"].default == 0.2
+    assert list(inspect.signature(M.log_sample_categorical).parameters)[:1] == ["logits"]
+    fwd = inspect.signature(M.ScorePosNet3D.forward)
+    assert list(fwd.parameters)[1:7] == ["ligand_pos_perturbed", "ligand_v_perturbed", "batch_ligand", "ligand_shape", "time_step", "return_all"]
+    with pytest.raises(RuntimeError):        # no CPU path here either
+        M.pointcloud_shape_guidance((np.zeros((8, 3)), None, 0.2), torch.zeros(3, 3))
+
+
+def test_chain_runner_registry_holds_no_strong_references():
+    """a model must not keep its ChainRunners (GBs of trajectory buffers) alive."""
+    import gc
+    import weakref
+    import shapemol_amd.runtime as R
+
+    class Dummy:                       # stands in for a runner: the registry is what is under test
+        pass
+    m = type("M", (), {})()
+    reg = m.__dict__.setdefault("_runners", weakref.WeakSet())
+    d = Dummy()
+    reg.add(d)
+    assert len(list(reg)) == 1
+    del d
+    gc.collect()
+    assert len(list(reg)) == 0
+    assert "WeakSet" in open(R.__file__).read()
+
+
 def test_driver_unbatch_matches_reference_loop_semantics():
     """shapemol_amd.sampling.unbatch == the per-step / per-molecule append loop of the reference driver
     (scripts/sample_diffusion.py:37-44,121-131), layouts and dtypes included."""

@@ -137,3 +137,50 @@ def test_diffusion_loss_oracle_golden(mode):
     for k in ("loss_pos", "loss_v", "loss"):
         assert abs(float(r[k]) - float(f[f"{mode}_{k}"])) < 1e-5 * max(1.0, abs(float(f[f"{mode}_{k}"]))), k
 
+
+
+# ---- the oracle at the sizes BASELINE.json names (round 3: these fixtures were only used against the HIP path before,
+# ---- while the cpu_baseline leg of bench.py and the B = 1024 / k = 32 GPU tests lean on the oracle at exactly these sizes)
+def test_forward_k32_b64_oracle_golden():
+    """configs[4] analogue from the reference: 64 molecules of 40-80 atoms (3.9k atoms), k = 32, full depth."""
+    f = golden("forward_k32_b64.npz")
+    sd, dm, _, _ = oracle_model(seed=9, knn=32)
+    bb = synth.synthetic_batch(64, seed=35, atoms_range=(40, 80))
+    assert np.array_equal(bb["counts"], f["counts"])
+    out = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(f["t"]))
+    for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
+        assert maxabs(out[k], f[k]) < FWD_TOL, k
+
+
+def _oracle_chain_against(c, steps, atoms_range=None, max_atoms=None, **model_kw):
+    sd, dm, _, _ = oracle_model(**model_kw)
+    B, seed, every, head = int(c["B"]), int(c["seed"]), int(c["every"]), int(c["head"])
+    bb = synth.synthetic_batch(B, seed=seed, atoms_range=atoms_range, max_atoms=max_atoms)
+    assert np.array_equal(bb["counts"], c["counts"])
+    n = len(bb["batch"])
+    r = O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), steps,
+                       lambda s: synth.step_noise(n, 15, s, seed=seed))
+    k = (steps - 1) // every + 1                       # snapshots covered by `steps` reverse steps
+    pos_traj, v_traj = torch.stack(r["pos_traj"]), torch.stack(r["v_traj"]).numpy()
+    assert np.array_equal(v_traj[::every][:k], c["v_traj_sub"][:k])
+    assert np.array_equal(v_traj[:head], c["v_traj_head"])
+    assert maxabs(pos_traj[::every][:k], c["pos_traj_sub"][:k]) < 1e-4
+    assert maxabs(pos_traj[:head], c["pos_traj_head"]) < 1e-5
+    assert maxabs(r["pos_cond_traj"][0], c["pos0_first"]) < FWD_TOL and maxabs(r["v0_traj"][0], c["v0_first"]) < 2 * FWD_TOL
+    if steps == int(c["S"]):
+        assert np.array_equal(r["v"].numpy(), c["v"])
+        assert maxabs(r["pos"], c["pos"]) < 1e-4
+        assert maxabs(r["vt_traj"][-1], c["vt_last"]) < 1e-4
+
+
+def test_chain_k32_b64_oracle_golden():
+    """The reference's 20-step chain at k = 32 (64 molecules of 40-80 atoms): all 20 steps, snapshots every 5."""
+    c = golden("chain_k32_b64_s20_hash.npz")
+    _oracle_chain_against(c, int(c["S"]), atoms_range=(40, 80), seed=9, knn=32)
+
+
+def test_chain_b1024_s50_oracle_golden():
+    """The reference's chain at the configs[2] / [3] per-GPU batch (1024 molecules, 21.9k atoms): all 50 steps, snapshots
+    every 10 (the oracle is the cpu_baseline of bench.py --batch 1024 and the checker of test_forward_b1024_vs_oracle)."""
+    c = golden("chain_b1024_s50_hash.npz")
+    _oracle_chain_against(c, int(c["S"]), max_atoms=38)

@@ -28,7 +28,7 @@ for B in (256, 64, 1024, 256):
     same = len(set(digests)) == 1
     ok &= same
     print(f"B={B:5d} atoms={len(bb['batch']):6d}: {a.reps} x 1000 steps in {time.time() - t0:.1f} s, digest {digests[0]} {'identical every time' if same else 'DIFFERENT: ' + str(digests)}", flush=True)
+    r.close()
     del r
-    m.__dict__["_runners"] = []
 print("soak OK" if ok else "soak FAILED")
 sys.exit(0 if ok else 1)
