@@ -211,9 +211,8 @@ def _refine(sd, dm, h, x, batch, shape, taps=None, bn_eval=False):
     return h, x
 
 
-@torch.no_grad()
-def score(sd, dm, pos, v, batch, shape, t, taps=None, bn_eval=False):
-    """One score evaluation.  pos (N,3) f32, v (N,) i64, batch (N,) i64 sorted, shape (B,S,3)
+def score_with_grad(sd, dm, pos, v, batch, shape, t, taps=None, bn_eval=False):
+    """One score evaluation, recorded by autograd (the training step's forward; score() is the same under no_grad).  pos (N,3) f32, v (N,) i64, batch (N,) i64 sorted, shape (B,S,3)
     f32, t (B,) i64 -> dict(pred_ligand_pos (N,3), pred_ligand_h (N,H), pred_ligand_v (N,C)).
     bn_eval: the module after .eval() (running batch-norm statistics)."""
     onehot = F.one_hot(v, dm.C).float()
@@ -222,6 +221,12 @@ def score(sd, dm, pos, v, batch, shape, t, taps=None, bn_eval=False):
     h, x = _refine(sd, dm, h, pos, batch, shape, taps, bn_eval)
     hv = F.softplus(_lin(sd, "v_inference.0", h)) - math.log(2.0)
     return {"pred_ligand_pos": x, "pred_ligand_h": h, "pred_ligand_v": _lin(sd, "v_inference.2", hv)}
+
+
+def score(sd, dm, pos, v, batch, shape, t, taps=None, bn_eval=False):
+    """score_with_grad without autograd (sampling, validation)."""
+    with torch.no_grad():
+        return score_with_grad(sd, dm, pos, v, batch, shape, t, taps, bn_eval)
 
 
 # ------------------------------------------------------------------------------------------
@@ -281,8 +286,16 @@ def _scatter_mean(val, batch, n_mols):
     return out / cnt.view(-1, *([1] * (val.dim() - 1)))
 
 
-@torch.no_grad()
-def diffusion_loss(sd, dm, pos, v, batch, shape, t, pos_noise, u, bn_eval=True, loss_v_weight=100.0, loss_weight_type="noise_level"):
+def diffusion_loss(sd, dm, pos, v, batch, shape, t, pos_noise, u, bn_eval=True, loss_v_weight=100.0, loss_weight_type="noise_level",
+                   with_grad=False):
+    """with_grad=False: as validate() evaluates it (no autograd).  with_grad=True: the training step's forward
+    (scripts/train_diffusion.py:135-147; bn_eval=False there), so that result['loss'].backward() yields the gradients of every
+    tensor of `sd` that requires grad -- the CPU check of the backward kernels (tests/golden/grad_b12.npz pins it)."""
+    with torch.set_grad_enabled(bool(with_grad)):
+        return _diffusion_loss(sd, dm, pos, v, batch, shape, t, pos_noise, u, bn_eval, loss_v_weight, loss_weight_type)
+
+
+def _diffusion_loss(sd, dm, pos, v, batch, shape, t, pos_noise, u, bn_eval, loss_v_weight, loss_weight_type):
     """get_diffusion_loss with eval_mode=True and given time steps (molopt_score_model.py:447-531; the form validate() of
     scripts/train_diffusion.py:168-192 calls, module in eval mode): perturb positions and atom types at t (pos_noise (N,3)
     is the normal_() draw of :461, u (N,C) the rand_like of log_sample_categorical inside q_v_sample :366-374), one score
@@ -297,7 +310,7 @@ def diffusion_loss(sd, dm, pos, v, batch, shape, t, pos_noise, u, bn_eval=True, 
                            sd["log_one_minus_alphas_cumprod_v"][tb].unsqueeze(-1), dm.C)
     v_pert = gumbel_argmax(log_qvt, u)
     log_vt = torch.log(F.one_hot(v_pert, dm.C).float().clamp(min=1e-30))
-    out = score(sd, dm, pos_pert, v_pert, batch, shape, t, bn_eval=bn_eval)
+    out = score_with_grad(sd, dm, pos_pert, v_pert, batch, shape, t, bn_eval=bn_eval)      # (autograd follows the caller's mode)
     pred_pos, pred_v = out["pred_ligand_pos"], out["pred_ligand_v"]
     log_recon = F.log_softmax(pred_v, dim=-1)
     log_model = _v_posterior(sd, dm, log_recon, log_vt, t, batch)

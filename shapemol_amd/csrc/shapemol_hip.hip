@@ -455,6 +455,7 @@ struct shapemol_ctx {
     ShapeTermArgs *prep_terms = nullptr; VnShapeArgs *prep_vn = nullptr; int n_prep_terms = 0;   // argument blocks of run_prep's two batched launches
     int2 *mol_span = nullptr;   // [N] molecule span of every atom
     float *xsum = nullptr;      // [N][3] per-atom sum of the h2x attention rows (folded coordinate update)
+    float *part_rows = nullptr, *part_ms = nullptr;   // k > 16: rows [2N][H] and softmax state [2N][heads][2] of the half-atom tiles
     float *alpha = nullptr;     // [N*KP][2][NT] attention weights handed from the key phase to the value phase
     float *x_a = nullptr, *x_b = nullptr, *x_state = nullptr, *pred_pos = nullptr, *pred_v = nullptr;
     int64_t *v_state = nullptr;
@@ -482,8 +483,9 @@ struct shapemol_ctx {
     int x2h_chain = 1;          // 1: x2h attention and the node stage of a layer in one launch (x2h_chain16_kernel) when every wave has one job
                                 // launch (measured: 28.5 us against 15.3 + 11.1 us, eight dependent weight blocks per wave)
     int node_f16 = 1;           // node kernels on two-piece f16 operands (sm_node16.h) instead of exactly split bf16 (sm_node.h)
-    int edge_tiles = 0;         // f16 edge kernels when the waves have several jobs: 0 = sliced launches of the one-job kernel [default],
-                                // 1 = one looping launch (one tile per wave-job), 2 = one looping launch, two tiles per wave-job (8 waves)
+    int wt_stores = 0;          // 1: write-through (sc1) stores of the per-node products (node_linear16_kernel)
+    int edge_tiles = -1;        // f16 edge kernels when the waves have several jobs: 0 = sliced launches of the one-job kernel,
+                                // 1 = one looping launch (eight waves per workgroup, next job's rows prefetched), -1 = automatic (= 1) [default]
     float hid_max = 0.f;        // bound of the edge MLPs' hidden activations (LayerNorm outputs): must fit fp16 for edge_bf16 = 3
     int num_cu = 256;
     // point-cloud shape guidance (shapemol_set_guidance)
@@ -564,6 +566,7 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
         A(&c->att, capN * H) || A(&c->o3, capN * 48) || A(&c->xsum, capN * 3) || A(&c->mol_span, capN) || A(&c->alpha, capN * c->KP * 2 * (H / 16)) || A(&c->pd, capN * hd * 6) || A(&c->x_a, capN * 3) ||
         A(&c->x_b, capN * 3) || A(&c->x_state, capN * 3) || A(&c->pred_pos, capN * 3) ||
         A(&c->pred_v, capN * g.num_classes) || A(&c->v_state, capN) || A(&c->stamps, 2048) || A(&c->kstamps, 8 * 16 * 4096) || A(&c->bn_acc, (size_t)L * kBnReplicas * 2 * hd + L + 1) ||
+        (c->KP > 16 && (A(&c->part_rows, (size_t)2 * capN * H) || A(&c->part_ms, (size_t)2 * capN * hd * 2))) ||
         A(&c->status, 8) || A(&c->chain_params, 1) || A(&c->prep_terms, 2 * L + 1) || A(&c->prep_vn, L))
         return 1;
     c->capN = capN; c->capB = capB;
@@ -600,7 +603,12 @@ bool vn_fold_ok(const shapemol_ctx *c, int n_atoms) {
     const int waves = std::max(4, std::min(12, (njobs + c->num_cu - 1) / c->num_cu));
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
     if (c->edge_threads > 0) return false;                                 // wave-count sweeps: keep the plain path
-    if (njobs > grid * waves && c->edge_tiles != 0) return false;         // looping launches: a workgroup's jobs are not contiguous
+    const int tiles_mode = c->edge_tiles >= 0 ? c->edge_tiles : 1;        // (as launch_edge16)
+    if (njobs > grid * waves && tiles_mode == 1) {                        // looping launches: a workgroup owns `chunk` consecutive jobs
+        const int lwv = 8;
+        const int lgrid = std::max(1, std::min(c->num_cu, (njobs + lwv - 1) / lwv)), chunk = (njobs + lgrid - 1) / lgrid;
+        return chunk * apj + 2 * (c->max_mol_atoms - 1) <= kVnFoldCap;
+    }
     const int waves_max = std::max(waves, c->cfg.hidden_dim / 16);          // the fused x2h + node-stage launch never uses fewer
     return waves_max * apj + 2 * (c->max_mol_atoms - 1) <= kVnFoldCap;
 }
@@ -623,16 +631,18 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)node_chain16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain16Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin16Chunk * 2 * H * 32));
 #define SETATTR4(K)                                                                                                   \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)x2h_chain16_kernel<H, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes));
-#define SETATTR5(K)                                                                                                   \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16x2_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16x2_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + 512 * 16));
-    if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) SETATTR5(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) SETATTR5(16) } else { SETATTR(32) SETATTR5(32) }
-#undef SETATTR5
+#define SETATTR6(K)                                                                                                   \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
+    if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) } else { SETATTR(32) SETATTR6(32) }
+#undef SETATTR6
 #undef SETATTR4
 #undef SETATTR3
 #undef SETATTR
@@ -684,55 +694,62 @@ template <int H, bool H2X>
 int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
     const int KP = c->KP;
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
-    if (KP <= 16) {
-        const int apj = 16 / KP;
-        const int njobs = (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
+    const int tiles_mode = c->edge_tiles >= 0 ? c->edge_tiles : 1;      // -1 = automatic: looping launches
+#define EDGE_DISPATCH(KERNEL, ...)                                                                  \
+    do {                                                                                            \
+        if (KP == 8) LAUNCH(nm, SMK((KERNEL<H, 8, H2X>), __VA_ARGS__));                             \
+        else if (KP == 16) LAUNCH(nm, SMK((KERNEL<H, 16, H2X>), __VA_ARGS__));                      \
+        else LAUNCH(nm, SMK((KERNEL<H, 32, H2X>), __VA_ARGS__));                                    \
+    } while (0)
+    {
+        // a job = one 16-slot tile: 16 / KP centre atoms (k <= 16) or half an atom (k > 16: two tiles per atom, merged afterwards)
+        const int apj = KP >= 16 ? 1 : 16 / KP;
+        const int njobs = KP > 16 ? 2 * a.n_atoms : (a.n_atoms + apj - 1) / apj, waves = edge_waves_for(c, njobs);
         const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
         const bool one = njobs <= grid * waves;      // every wave has at most one job: straight-line instantiation
-        const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
-                           + (H2X ? (size_t)vn_red_doubles(waves, H / 8) * 8 + (size_t)waves * apj * 48 * 4 : (a.vf.enable ? kVnFoldBytes : 0));
-        if (one || c->edge_tiles == 0) {
-            // larger batches (edge_tiles = 0): several launches of the straight-line instantiation, each over a slice of
-            // grid x waves jobs (no spills, full overlap inside a launch; the image fill is paid per slice)
-            // ... of equal size: the jobs are spread evenly over the fewest launches that can hold them (a last slice that
-            // is nearly empty costs a full launch floor)
-            int ws = waves, gs = grid;
-            if (!one && c->edge_threads == 0) {      // (an explicit edge_waves option keeps its wave count)
-                const int nsl = (njobs + c->num_cu * 12 - 1) / (c->num_cu * 12), target = (njobs + nsl - 1) / nsl;
-                ws = std::max(4, std::min(12, (target + c->num_cu - 1) / c->num_cu));
-                gs = std::max(1, std::min(c->num_cu, (target + ws - 1) / ws));
-            }
-            const int per = gs * ws;
-            const size_t shm_s = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
-                                 + (H2X ? (size_t)vn_red_doubles(ws, H / 8) * 8 + (size_t)ws * apj * 48 * 4 : (a.vf.enable ? kVnFoldBytes : 0));
-            for (int base = 0; base < njobs; base += per) {
-                Edge16Args b = a;
-                b.job_base = base; b.job_end = std::min(njobs, base + per); b.nwave = ws;
-                const int g2 = std::max(1, std::min(gs, (b.job_end - base + ws - 1) / ws));
-                if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, true>), dim3(g2), dim3(ws * 64), shm_s, s, b));
-                else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, true>), dim3(g2), dim3(ws * 64), shm_s, s, b));
-            }
+        auto shm_for = [&](int w) {
+            return (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float)
+                   + (H2X ? (size_t)vn_red_doubles(w, H / 8) * 8 + (size_t)w * apj * 48 * 4 : (a.vf.enable ? kVnFoldBytes : 0));
+        };
+        if (!one && tiles_mode == 1) {
+            // looping launch: eight waves per workgroup (two per SIMD, 256 VGPRs: a job's state plus the next job's gathered rows
+            // without spilling), every workgroup owns `chunk` consecutive jobs
+            const int lw = c->edge_threads > 0 ? std::min(8, c->edge_threads / 64) : 8;
+            const int lgrid = std::max(1, std::min(c->num_cu, (njobs + lw - 1) / lw));
+            Edge16Args b = a;
+            b.job_base = 0; b.job_end = njobs; b.nwave = lw; b.chunk = (njobs + lgrid - 1) / lgrid;
+            const int g2 = (njobs + b.chunk - 1) / b.chunk;
+            EDGE_DISPATCH(edge16_loop_kernel, dim3(g2), dim3(lw * 64), shm_for(lw), s, b);
             return 0;
         }
-        if (c->edge_tiles == 1) {
+        // one launch of the straight-line instantiation, or (larger batches, edge_tiles = 0) several, each over a slice of
+        // grid x waves jobs (no spills, full overlap inside a launch; the image fill is paid per slice)
+        // ... of equal size: the jobs are spread evenly over the fewest launches that can hold them (a last slice that
+        // is nearly empty costs a full launch floor)
+        int ws = waves, gs = grid;
+        if (!one && c->edge_threads == 0) {      // (an explicit edge_waves option keeps its wave count)
+            const int nsl = (njobs + c->num_cu * 12 - 1) / (c->num_cu * 12), target = (njobs + nsl - 1) / nsl;
+            ws = std::max(4, std::min(12, (target + c->num_cu - 1) / c->num_cu));
+            gs = std::max(1, std::min(c->num_cu, (target + ws - 1) / ws));
+        }
+        const int per = gs * ws;
+        for (int base = 0; base < njobs; base += per) {
             Edge16Args b = a;
-            b.nwave = waves;
-            if (KP == 8) LAUNCH(nm, SMK((edge16_kernel<H, 8, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, b));
-            else LAUNCH(nm, SMK((edge16_kernel<H, 16, H2X, false>), dim3(grid), dim3(waves * 64), shm, s, b));
-            return 0;
+            b.job_base = base; b.job_end = std::min(njobs, base + per); b.nwave = ws;
+            const int g2 = std::max(1, std::min(gs, (b.job_end - base + ws - 1) / ws));
+            EDGE_DISPATCH(edge16_kernel, dim3(g2), dim3(ws * 64), shm_for(ws), s, b);
         }
     }
-    // two tiles per wave-job, eight waves per workgroup: several jobs per wave (large batches) and k > 16
-    const int apj2 = KP == 32 ? 1 : 32 / KP;
-    const int njobs = (a.n_atoms + apj2 - 1) / apj2;
-    const int waves = c->edge_threads > 0 ? std::min(8, c->edge_threads / 64) : 8;      // option edge_waves (sweeps); 8 = two per SIMD
-    const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
-    const size_t shm = (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, (H2X ? 1 : H / 16)>::TOTAL) * sizeof(float) + (H2X ? 512 * 16 : 0);
-    Edge16Args b2 = a;
-    b2.nwave = waves;
-    if (KP == 8) LAUNCH(nm, SMK((edge16x2_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, b2));
-    else if (KP == 16) LAUNCH(nm, SMK((edge16x2_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, b2));
-    else LAUNCH(nm, SMK((edge16x2_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, b2));
+#undef EDGE_DISPATCH
+    return 0;
+}
+
+// k > 16: merge the two half-atom tiles of every atom (combine32_kernel) into `out` ([N][H] or [N][48])
+template <bool H2X>
+int launch_combine32(shapemol_ctx *c, hipStream_t s, float *out, int n_atoms) {
+    Combine32Args ca{c->part_rows, c->part_ms, out, n_atoms, c->cfg.n_heads, c->cfg.hidden_dim / 16};
+    const int items = n_atoms * (H2X ? 48 : c->cfg.hidden_dim / 4);
+    LAUNCH("edge_combine", SMK(combine32_kernel<H2X>, dim3((items + 255) / 256), dim3(256), 0, s, ca));
     return 0;
 }
 
@@ -783,7 +800,7 @@ int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float 
     const int tpg = std::max(1, (n_ct + want_groups - 1) / want_groups);
     const int agroups = (n_ct + tpg - 1) / tpg;
     const bool f16 = c->lin_bf16 && c->node_f16;
-    NodeLinArgs a{in, f16 ? wimg16 : (c->lin_bf16 ? wimg6 : wimg), add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps, nwave};
+    NodeLinArgs a{in, f16 ? wimg16 : (c->lin_bf16 ? wimg6 : wimg), add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps, nwave, c->wt_stores};
     if (f16) {
         const size_t shm = (size_t)std::min(tpg, kLin16Chunk) * 2 * H * 32;
         LAUNCH(name, SMK(node_linear16_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a, c->status + ST_RANGE));
@@ -894,6 +911,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         const bool phases = c->edge_bf16 && KP <= 16;
         const bool f16 = c->edge_bf16 == 3;     // two-piece f16 operands (sm_edge16.h), the default
         const bool xc_fused = f16 && x2h_chain_ok<H>(c, n);
+        const bool half_tiles = f16 && KP > 16;          // k > 16: two 16-slot tiles per atom + combine
         Edge16Args xea{};
         if (f16) {   // x2h attention: both MLP images resident, one barrier
             Edge16Args &ea = xea;
@@ -901,7 +919,9 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             ea.pre = l == 0 ? c->pre0 : c->preAB + 4 * H; ea.q = c->q_x; ea.x = cur_x; ea.nbr = c->nbr; ea.ew = c->ew; ea.out = c->att;
             ea.n_atoms = n; ea.ld_pre = l == 0 ? 4 * H : 8 * H; ea.stamps = (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr;
             ea.vf = pending; pending = VnFold{};
+            if (half_tiles) { ea.out = c->part_rows; ea.part_ms = c->part_ms; }       // k > 16: per-tile rows, merged below
             if (!xc_fused && launch_edge16<H, false>(c, s, ea)) return 1;     // (fused: launched with the node stage below)
+            if (half_tiles && launch_combine32<false>(c, s, c->att, n)) return 1;
         } else if (phases && c->edge_bf16 == 1) {   // x2h attention, key and value phase in one launch
             EdgeFusedArgs fa{c->P(Dl.img_kx), c->P(Dl.img_vx), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew,
                              c->alpha, c->att, n, l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
@@ -946,7 +966,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             ea.image_k = c->P(Dl.i16_kh); ea.image_v = c->P(Dl.i16_vh);
             ea.pre = c->preAB; ea.q = c->q_h; ea.x = cur_x; ea.nbr = c->nbr; ea.ew = c->ew; ea.out = c->o3;
             ea.n_atoms = n; ea.ld_pre = 8 * H; ea.stamps = (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr;
-            if (c->vn_fuse) {
+            if (half_tiles) { ea.out = c->part_rows; ea.part_ms = c->part_ms; }       // (no fused VN-linear: vn_stats / vn_apply below)
+            if (c->vn_fuse && !half_tiles) {
                 ea.vn = {c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o), c->P(Dl.wd_o),
                          c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd,
                          nullptr, c->status + ST_VN_BARRIER, x_next, 2};
@@ -964,6 +985,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                 }
             }
             if (launch_edge16<H, true>(c, s, ea)) return 1;
+            if (half_tiles && launch_combine32<true>(c, s, c->o3, n)) return 1;
         } else if (phases) {   // h2x attention, both images resident in LDS (exactly split bf16 operands)
             EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H,
                              (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
@@ -1279,8 +1301,9 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
         if (value == 3 && c->hid_max > 6.0e4f) return fail("edge_bf16 = 3: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights");
         c->edge_bf16 = (int)value;
     }
-    else if (k == "edge_tiles") { if (value < 0 || value > 2) return fail("edge_tiles must be 0, 1 or 2"); c->edge_tiles = (int)value; }
+    else if (k == "edge_tiles") { if (value < -1 || value > 1) return fail("edge_tiles must be -1 (automatic), 0 (sliced one-job launches) or 1 (looping launch)"); c->edge_tiles = (int)value; }
     else if (k == "node_f16") c->node_f16 = value != 0;
+    else if (k == "wt_stores") c->wt_stores = value != 0;
     else if (k == "lin_fuse") c->lin_fuse = value != 0;
     else if (k == "x2h_chain") c->x2h_chain = value != 0;
     else if (k == "graph_fuse") c->graph_fuse = value != 0;

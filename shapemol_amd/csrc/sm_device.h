@@ -51,6 +51,13 @@ SM_DEV f32x4 mfma16(float a, float b, f32x4 c) {
 
 SM_DEV float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 SM_DEV void stg4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// 16-byte write-through store (sc1): the line leaves the XCD's L2 while the kernel runs instead of staying dirty until the
+// end-of-kernel write-back (a dependent kernel boundary costs + dirty bytes / ~6 TB/s: 22.7 MB of per-node products = 3.8 us),
+// and it is not kept in this XCD's L2, whose other seven eighths of the readers could not use it anyway.
+SM_DEV void stg4_wt(float *p, float4 v) {
+    const f32x4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+}
 
 // Cooperative global -> LDS copy of `n4` float4 by all `nthr` threads of the workgroup, eight
 // independent 16-byte loads in flight per thread (a plain copy loop is serialised on the L2 latency).
@@ -352,6 +359,18 @@ SM_DEV f32x4 tile_bf16x6(const unsigned *w, int t2, const u32x4 (&bh)[NT / 2], c
 // even lane groups own the logits of blocks 0 .. NT/2-1 and the odd groups those of NT/2 .. NT-1 (no lane
 // repeats another's softmax); the softmax runs over the SEGW neighbour slots of the atom (a DPP row segment).
 // alpha[t] belongs to head block t + (NT/2) * (g & 1).
+template <int NT, int SEGW>
+SM_DEV float attention_weight_pair(float4 qa, float4 qb, f32x4 ka, f32x4 kb, bool ok, float &mx, float &s) {
+    float pa = qa.x * ka[0] + qa.y * ka[1] + qa.z * ka[2] + qa.w * ka[3];
+    float pb = qb.x * kb[0] + qb.y * kb[1] + qb.z * kb[2] + qb.w * kb[3];
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(pa), "+v"(pb));
+    float p = pa + pb;
+    p = ok ? p * 0.35355339059327373f : -INFINITY;
+    mx = seg_max<SEGW>(p);
+    const float e = ok ? fast_exp(p - mx) : 0.f;
+    s = seg_sum<SEGW>(e);
+    return s > 0.f ? e * __builtin_amdgcn_rcpf(s) : 0.f;
+}
 template <int NT, int SEGW>
 SM_DEV float attention_weight_pair(float4 qa, float4 qb, f32x4 ka, f32x4 kb, bool ok) {
     float pa = qa.x * ka[0] + qa.y * ka[1] + qa.z * ka[2] + qa.w * ka[3];

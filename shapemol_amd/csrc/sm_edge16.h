@@ -136,26 +136,41 @@ struct Edge16Args {
     int job_base, job_end;            // edge16_kernel: this launch covers jobs [job_base, job_end) (job_end = 0: all of them)
     int nwave;                        // waves per workgroup (= blockDim.x / 64; as an argument because reading blockDim costs
                                       // two dependent loads from the implicit kernel arguments at the head of every launch)
+    int chunk;                        // looping launches (edge16_loop_kernel): consecutive jobs per workgroup; its waves take
+                                      // them round robin (job = first + wave, + nwave, ...)
     unsigned long long *stamps;       // diagnostic build only
     EdgeFusedArgs::VnFuse vn;         // h2x: VN-linear + batch statistics behind the attention (enable = 0 or 2)
     float *xsum;                      // h2x with vn.enable: [N][3] sum of the attention rows per atom (for a following VnFold), or nullptr
     VnFold vf;                        // x2h: coordinate update of the previous layer in the prologue
+    float *part_ms;                   // KP = 32: [2 N][heads][2] running max and sum of every half-atom tile's softmax (see below)
 };
 
 // ONE = true: every wave has at most one job (jobs <= workgroups x waves; the common case up to ~6k atoms).
+// ONE = false (edge16_loop_kernel, two waves per SIMD): a workgroup owns a.chunk consecutive jobs, its waves loop over them
+// round robin and request the NEXT job's key rows under the current job's value MLP (the 256-VGPR budget of two waves per
+// SIMD holds a job's state and the next job's 64 gathered registers without spilling; with three waves per SIMD -- 168
+// VGPRs -- the looping form spilled 54-75 registers and lost to sliced launches of the one-job form).
 // KEEP (x2h, ONE): the attention rows are not stored; the storing lanes (n % SEGW == 0: lane (n, g) owns features
 // 16 t + 4 g .. + 3 of centre atom n / SEGW of the wave's job) return them in keep[t] for a node stage fused behind
 // (x2h_chain16_kernel, sm_node16.h); all other lanes return zeros.
+//
+// KP = 32 (k > 16): an atom's 32 neighbour slots are TWO jobs, one 16-slot tile each (jobs 2 a and 2 a + 1), run like any
+// other tile with the softmax taken over the tile's own slots; each tile stores its rows (normalised inside the tile) to
+// a.out[job] and the running maximum m and sum s of every head's softmax to a.part_ms[job], and combine32_kernel merges the
+// two tiles of an atom with the weights s_t exp(m_t - M) / sum_t s_t exp(m_t - M) (the "online softmax" identity).  No wave
+// ever holds two tiles, so k = 32 runs in the same registers as k = 8 (the two-tile kernel of round 2 needed 256 VGPRs and
+// spilled 40-75); the VN-linear epilogue is not fused for k > 16 (vn_stats_kernel / vn_apply_kernel follow the combine).
 template <int H, int KP, bool H2X, bool ONE, bool KEEP>
 SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
-    static_assert(KP == 8 || KP == 16, "single-tile jobs");
-    static_assert(!KEEP || (ONE && !H2X), "KEEP: one-job x2h only");
+    static_assert(KP == 8 || KP == 16 || KP == 32, "16-slot tiles");
+    static_assert(!KEEP || (ONE && !H2X && KP <= 16), "KEEP: one-job x2h only");
     constexpr int NT = H / 16;
     constexpr int NT2V = H2X ? 1 : NT;
     using IMK = EdgeImage16<H, NT>;
     using IMV = EdgeImage16<H, NT2V>;
     constexpr int V_BASE = IMK::TOTAL;
-    constexpr int APJ = 16 / KP, SEGW = KP;
+    constexpr bool HALF = KP == 32;                               // a job is half an atom
+    constexpr int SEGW = KP >= 16 ? 16 : KP, APJ = 16 / SEGW;
     constexpr int HD = H / 8;                                     // heads = VN channels
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -163,10 +178,12 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
     const int n = lane & 15, g = lane >> 4;
     float cen[5];
     rbf_centres(g, cen);
-    const int njobs_all = (a.n_atoms + APJ - 1) / APJ;
+    const int njobs_all = HALF ? 2 * a.n_atoms : (a.n_atoms + APJ - 1) / APJ;
     const int njobs = a.job_end > 0 ? min(a.job_end, njobs_all) : njobs_all;       // a launch may cover a slice of the jobs
-    const int jstride = gridDim.x * nwave;
-    const int job0 = a.job_base + blockIdx.x * nwave + wave;
+    const int chunk = ONE ? nwave : a.chunk;                                       // consecutive jobs of this workgroup
+    const int wg_first = a.job_base + blockIdx.x * chunk, wg_end = min(njobs, wg_first + chunk);
+    const int jstride = nwave;
+    const int job0 = wg_first + wave;
 
     int atom = 0, jn = 0, edge = 0;
     bool atom_ok = false, ok = false;
@@ -179,12 +196,23 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
 
     // the key MLP's rows are requested up front: the centre atom's first (they do not wait for the neighbour index),
     // then the neighbour's
+    auto atom_of_job = [&](int jb) { return HALF ? (jb >> 1) : jb * APJ + n / SEGW; };
+    auto slot_of_job = [&](int jb) { return HALF ? 16 * (jb & 1) + n : n % SEGW; };
     auto locate = [&](int jb) {      // -> the job's neighbour index (a load: issue it before anything else of the job)
-        const int atom_raw = jb * APJ + n / SEGW;
+        const int atom_raw = atom_of_job(jb);
         atom_ok = atom_raw < a.n_atoms;
         atom = atom_ok ? atom_raw : a.n_atoms - 1;
-        edge = atom * KP + n % SEGW;
+        edge = atom * KP + slot_of_job(jb);
         return a.nbr[edge];
+    };
+    auto peek = [&](int jb) {        // the same load without adopting the job (the next job's index, requested a phase early)
+        return a.nbr[min(atom_of_job(jb), a.n_atoms - 1) * KP + slot_of_job(jb)];
+    };
+    auto adopt = [&](int jb) {       // the bookkeeping of locate() for an index that peek() has already fetched
+        const int atom_raw = atom_of_job(jb);
+        atom_ok = atom_raw < a.n_atoms;
+        atom = atom_ok ? atom_raw : a.n_atoms - 1;
+        edge = atom * KP + slot_of_job(jb);
     };
     auto request = [&](int jraw) {
         const float *pi = a.pre + (size_t)(SM_ABL(17) ? 0 : atom) * a.ld_pre;
@@ -207,14 +235,14 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
     };
     // the value MLP's rows and the query row are requested once the key rows have been consumed (register budget): they
     // fly under the key MLP's hidden layer (all of whose other operands come from LDS)
-    auto request_2 = [&]() {
+    auto request_2 = [&](int atom, int jn) {
         const float *pi = a.pre + (size_t)(SM_ABL(17) ? 0 : atom) * a.ld_pre + 2 * H, *pj = a.pre + (size_t)(SM_ABL(17) ? 0 : jn) * a.ld_pre + 3 * H;
 #pragma unroll
         for (int t = 0; t < NT; ++t) { gav[t] = ldg4(pi + 16 * t + 4 * g); gbv[t] = ldg4(pj + 16 * t + 4 * g); }
     };
     // the query row: requested once the value rows have been consumed (it is first used by the key phase, after the value
     // MLP's hidden layer), so that it does not hold 32 registers beside them
-    auto request_q = [&]() {
+    auto request_q = [&](int atom) {
         const float *qrow = a.q + (size_t)atom * H + 4 * g;
 #pragma unroll
         for (int t = 0; t < NT; ++t) qv[t] = ldg4(qrow + 16 * t);
@@ -241,7 +269,7 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
         split_act16<NT>(hid, bh, bl);
     };
 
-    const bool have0 = job0 < njobs;
+    const bool have0 = job0 < wg_end;
     if constexpr (KEEP) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) keep[t] = float4{0.f, 0.f, 0.f, 0.f};
@@ -259,8 +287,8 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
     if constexpr (!H2X) {
         if (fold) {
             double *sred = reinterpret_cast<double *>(xt + 3 * kVnFoldCap);          // [2][16] batch sums
-            const int first_atom = (a.job_base + blockIdx.x * nwave) * APJ;
-            const int last_atom = min(a.n_atoms, first_atom + nwave * APJ) - 1;
+            const int first_atom = wg_first * APJ;
+            const int last_atom = min(a.n_atoms, wg_end * APJ) - 1;
             if (first_atom <= last_atom) {
                 span0 = a.vf.mol_span[first_atom].x;
                 const int span = a.vf.mol_span[last_atom].y - span0;
@@ -322,21 +350,36 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
     __syncthreads();
     SM_TICK(a.stamps, 1);
 
-    const float *imk = lds, *imv = lds + V_BASE;
-    const unsigned *w2k = reinterpret_cast<const unsigned *>(imk) + IMK::O_W2;
-    const unsigned *w2v = reinterpret_cast<const unsigned *>(imv) + IMV::O_W2;
     // fused coordinate update (h2x): scratch behind the images
     double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);
-    float *vn_o = reinterpret_cast<float *>(vn_red + vn_red_doubles(nwave, HD)) + wave * (APJ * 48);   // this wave's attention rows [APJ][16][3]
-    const bool one_job = njobs - a.job_base <= jstride;
+    auto vn_rows = [&]() { return reinterpret_cast<float *>(vn_red + vn_red_doubles(nwave, HD)) + wave * (APJ * 48); };   // this wave's attention rows [APJ][16][3] (formed where it is used: one register less across the MLPs)
+    const bool one_job = ONE;                                 // (looping launches read their attention rows back through L2)
 
-    bool first = true;
-    for (int job = job0; job < njobs; job += jstride) {
-        if constexpr (!ONE) asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
-        if (!first) request(locate(job));
-        first = false;
+    for (int job = job0; job < wg_end; job += jstride) {
+        // Looping launches: the image spans more than the 64 KB a DS instruction's offset field reaches, so the compiler forms
+        // some thirty LDS base addresses -- and, in a loop, hoists all of them out of it as loop invariants and SPILLS them
+        // (54-75 registers at the 168-VGPR budget; the reloads wait behind the row gathers).  An offset the compiler cannot
+        // see through (always 0) keeps the address arithmetic inside the iteration, next to its use, as in the one-job form;
+        // the memory clobber keeps the (loop-invariant) weight reads themselves inside the loop.
+        int lds_opq = 0;
+        if constexpr (!ONE) asm volatile("" : "+v"(lds_opq) : : "memory");
+        if constexpr (!ONE) SM_TICK(a.stamps, 6);
+        const float *imk = lds + lds_opq, *imv = lds + V_BASE + lds_opq;
+        const unsigned *w2k = reinterpret_cast<const unsigned *>(imk) + IMK::O_W2;
+        const unsigned *w2v = reinterpret_cast<const unsigned *>(imv) + IMV::O_W2;
+        if constexpr (!ONE) rbf_centres(g + lds_opq, cen);     // (five more loop invariants the allocator would rather spill)
+        // the job at hand (the request variables are handed to the next job below, under this job's value MLP)
+        bool have_next = false;
+        int jraw_next = 0;
+        const int c_atom = atom, c_jn = jn;
+        const bool c_ok = ok, c_atom_ok = atom_ok;
+        const float c_wgt = wgt;
+        if constexpr (!ONE) {
+            have_next = job + jstride < wg_end;
+            if (have_next) jraw_next = peek(job + jstride);  // old by the time its gathers are issued: nothing waits for it
+        }
         if (fold) {      // coordinates from the table the prologue built (the barrier above made it visible)
-            const int ia = min(max(atom - span0, 0), span_n - 1) * 3, ja = min(max(jn - span0, 0), span_n - 1) * 3;
+            const int ia = min(max(c_atom - span0, 0), span_n - 1) * 3, ja = min(max(c_jn - span0, 0), span_n - 1) * 3;
 #pragma unroll
             for (int k = 0; k < 3; ++k) { xi[k] = xt[ia + k]; xj[k] = xt[ja + k]; }
         }
@@ -352,12 +395,13 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
         }
         // ---- hidden activations of both MLPs, then the two second Linears back to back from registers ----------------
         u32x4 kh[NT / 2], kl[NT / 2], vh[NT / 2], vl[NT / 2];
+        auto after_value_rows = [&]() { request_q(c_atom); };      // the value rows have been consumed: the query row
         if (!SM_ABL(18)) {
-            hidden(imk, IMK{}, ga, gb, rh, rl, kh, kl, request_2);
+            hidden(imk, IMK{}, ga, gb, rh, rl, kh, kl, [&]() { request_2(c_atom, c_jn); });
             SM_TICK(a.stamps, 2);
-            hidden(imv, IMV{}, gav, gbv, rh, rl, vh, vl, request_q);
+            hidden(imv, IMV{}, gav, gbv, rh, rl, vh, vl, after_value_rows);
         } else {
-            request_2(); request_q();
+            request_2(c_atom, c_jn); after_value_rows();
 #pragma unroll
             for (int b = 0; b < NT / 2; ++b) {
                 kh[b] = u32x4{__builtin_bit_cast(unsigned, ga[b].x + gb[b].x), rh[1], rh[2], rl[0]}; kl[b] = rl; vh[b] = kh[b];
@@ -381,14 +425,24 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
                     na = tile_f16x3<NT, NT>(w2k, t + 1, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
                     nb = tile_f16x3<NT, NT>(w2k, t + 1 + NT / 2, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
                 }
-                alpha[t] = attention_weight_pair<NT, SEGW>(qv[t], qv[t + NT / 2], ka, kb, ok);
+                if constexpr (HALF) {        // this tile's softmax state of head 2 (t + (NT/2)(g & 1)) + (g >> 1), for the combine
+                    float mx, ssum;
+                    alpha[t] = attention_weight_pair<NT, SEGW>(qv[t], qv[t + NT / 2], ka, kb, c_ok, mx, ssum);
+                    if (n == 0 && c_atom_ok)
+                        *reinterpret_cast<float2 *>(a.part_ms + ((size_t)job * HD + 2 * (t + (NT / 2) * (g & 1)) + (g >> 1)) * 2) = float2{mx, ssum};
+                } else alpha[t] = attention_weight_pair<NT, SEGW>(qv[t], qv[t + NT / 2], ka, kb, c_ok);
                 ka = na; kb = nb;
             }
         }
         SM_TICK(a.stamps, 4);
+        // looping launches: the NEXT job's key rows are requested here, once the key MLP's fragments and the query row are dead,
+        // and fly under the value MLP's second Linear (and the partner wave's work)
+        if constexpr (!ONE) {
+            if (have_next) { adopt(job + jstride); request(jraw_next); }
+        }
         // ---- value phase ----------------------------------------------------------------------------------------------
-        const float w = ok ? wgt : 0.f;
-        const bool store = atom_ok && (n % SEGW) == 0;
+        const float w = c_ok ? c_wgt : 0.f;
+        const bool store = c_atom_ok && (n % SEGW) == 0;
         {
             const float *b2 = imv + IMV::O_B2;
             if constexpr (!H2X) {
@@ -403,7 +457,7 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
                 }
                 // sum_j a_ij (W2 hid_ij + b2) = sum_j a_ij W2 hid_ij + b2 sum_j a_ij: the bias enters through the per-head sum
                 // of the weights, so the accumulators start at zero and b2 is only needed by the storing lanes at the end
-                float *op = a.out + (size_t)atom * H;
+                float *op = a.out + (size_t)(HALF ? job : c_atom) * H;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const f32x4 v = SM_ABL(20) ? f32x4{__builtin_bit_cast(float, vh[t % (NT / 2)][0] & 0x3fffffffu), 1.f, 2.f, 3.f}
@@ -430,12 +484,12 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
                     for (int k = 0; k < 3; ++k) o[3 * r + k] = seg_sum<SEGW>(av * rel[k]);
                 }
                 if (store) {
-                    float *op = a.out + (size_t)atom * 48 + 12 * g;
+                    float *op = a.out + (size_t)(HALF ? job : c_atom) * 48 + 12 * g;
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
                         stg4(op + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
                     if (a.vn.enable && one_job) {           // keep the rows at hand for the VN-linear below (no L2 round trip)
-                        float *ol = vn_o + (n / SEGW) * 48 + 12 * g;
+                        float *ol = vn_rows() + (n / SEGW) * 48 + 12 * g;
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
                             stg4(ol + 4 * i, float4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]});
@@ -447,7 +501,7 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
         if constexpr (ONE) break;
     }
 
-    if constexpr (H2X) {
+    if constexpr (H2X && !HALF) {
         if (!a.vn.enable) return;
         // ---- VN-linear of this wave's atoms: p, d per channel from the 16 attention rows (+ x, + shape term) and the
         //      batch sums of ||p|| (shape_vn_layers.py:41-61,95-110): lane = (atom of the job, channel) ----
@@ -455,11 +509,11 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
         const bool v_lane = v_al < APJ && v_c < HD;
         double v_s1 = 0.0, v_s2 = 0.0;
         if (!one_job) __syncthreads();               // rows come back through L2: drain this workgroup's stores first
-        for (int jb = job0; jb < njobs; jb += jstride) {
+        for (int jb = job0; jb < wg_end; jb += jstride) {
             const int va = jb * APJ + v_al;
             if (v_lane && va < a.n_atoms) {
                 float orow[48];
-                const float *ov = one_job ? vn_o + v_al * 48 : a.out + (size_t)va * 48;
+                const float *ov = one_job ? vn_rows() + v_al * 48 : a.out + (size_t)va * 48;
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
                     const float4 t = ldg4(ov + 4 * i);
@@ -519,302 +573,51 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
     }
 }
 
-template <int H, int KP, bool H2X, bool ONE = false>
+template <int H, int KP, bool H2X>
 __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
-edge16_kernel(Edge16Args a) {
+edge16_kernel(Edge16Args a) {          // one job per wave, up to twelve waves per workgroup
     float4 keep[H / 16];
-    edge16_body<H, KP, H2X, ONE, false>(a, keep);
-}
-
-// -------------------------------------------------------------------------------------------------------------------
-// Throughput instantiation: TWO 16-column tiles per wave-job, several jobs per wave, two waves per SIMD (8 per
-// workgroup, 256 VGPRs).  Used when the waves have more than one job each (batches beyond ~6k atoms) and for k > 16:
-//   KP = 8 / 16 : the two tiles are independent (4 / 2 centre atoms per job), softmax inside each tile as above;
-//   KP = 32     : one centre atom per job, its 32 neighbour slots span both tiles; max and sum of the softmax and the
-//                 weighted neighbour sums are combined across the two tiles in registers (same wave).
-// Every A fragment read from LDS feeds both tiles (half the LDS traffic per matrix instruction), and the next job's
-// key rows are requested before the value MLP's second Linear of the current job.
-// -------------------------------------------------------------------------------------------------------------------
-template <int NT, int NT2>
-SM_DEV void tile2_f16x3(const unsigned *w2, int t2, const u32x4 (&bh0)[NT / 2], const u32x4 (&bl0)[NT / 2],
-                        const u32x4 (&bh1)[NT / 2], const u32x4 (&bl1)[NT / 2], f32x4 &c0, f32x4 &c1, int lane) {
-    constexpr int NB = NT / 2;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const u32x4 ah = *reinterpret_cast<const u32x4 *>(w2 + (((0 * NT2 + t2) * NB + b) * 64 + lane) * 4);
-        const u32x4 al = *reinterpret_cast<const u32x4 *>(w2 + (((1 * NT2 + t2) * NB + b) * 64 + lane) * 4);
-        c0 = mfma_f16(al, bh0[b], c0); c1 = mfma_f16(al, bh1[b], c1);
-        c0 = mfma_f16(ah, bl0[b], c0); c1 = mfma_f16(ah, bl1[b], c1);
-        c0 = mfma_f16(ah, bh0[b], c0); c1 = mfma_f16(ah, bh1[b], c1);
-    }
+    edge16_body<H, KP, H2X, true, false>(a, keep);
 }
 
 template <int H, int KP, bool H2X>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-edge16x2_kernel(Edge16Args a) {
-    static_assert(KP == 8 || KP == 16 || KP == 32, "two tiles per job");
-    constexpr int NT = H / 16;
-    constexpr int NT2V = H2X ? 1 : NT;
-    using IMK = EdgeImage16<H, NT>;
-    using IMV = EdgeImage16<H, NT2V>;
-    constexpr int V_BASE = IMK::TOTAL;
-    constexpr bool WIDE = KP == 32;                               // one atom across both tiles
-    constexpr int SEGW = KP >= 16 ? 16 : KP;                      // lanes of one atom inside a tile
-    constexpr int APT = 16 / SEGW;                                // atoms per tile
-    constexpr int APJ = WIDE ? 1 : 2 * APT;                       // atoms per job
-    constexpr int HD = H / 8;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+edge16_loop_kernel(Edge16Args a) {     // eight waves per workgroup looping over a.chunk consecutive jobs
+    float4 keep[H / 16];
+    edge16_body<H, KP, H2X, false, false>(a, keep);
+}
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = a.nwave;
-    const int n = lane & 15, g = lane >> 4;
-    float cen[5];
-    rbf_centres(g, cen);
-    const int njobs = (a.n_atoms + APJ - 1) / APJ;
-    const int jstride = gridDim.x * nwave;
-    const int job0 = blockIdx.x * nwave + wave;
-
-    int atom[2], jn[2], edge[2];
-    bool atom_ok[2], ok[2];
-    float xi[2][3], xj[2][3], wgt[2];
-    float4 ga[2][NT], gb[2][NT];
-
-    auto locate = [&](int jb, int tl) {
-        const int atom_raw = WIDE ? jb : jb * APJ + tl * APT + n / SEGW;
-        atom_ok[tl] = atom_raw < a.n_atoms;
-        atom[tl] = atom_ok[tl] ? atom_raw : a.n_atoms - 1;
-        edge[tl] = atom[tl] * KP + (WIDE ? 16 * tl + n : n % SEGW);
-        const int jraw = a.nbr[edge[tl]];
-        ok[tl] = atom_ok[tl] && jraw >= 0;
-        jn[tl] = ok[tl] ? jraw : atom[tl];
-    };
-    auto request = [&](int tl) {      // key-MLP rows of one tile
-        const float *pi = a.pre + (size_t)atom[tl] * a.ld_pre, *pj = a.pre + (size_t)jn[tl] * a.ld_pre + H;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { ga[tl][t] = ldg4(pi + 16 * t + 4 * g); gb[tl][t] = ldg4(pj + 16 * t + 4 * g); }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { xi[tl][k] = a.x[atom[tl] * 3 + k]; xj[tl][k] = a.x[jn[tl] * 3 + k]; }
-        wgt[tl] = a.ew[edge[tl]];
-    };
-    auto request_v = [&]() {          // value-MLP rows (the key rows have been consumed)
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            const float *pi = a.pre + (size_t)atom[tl] * a.ld_pre + 2 * H, *pj = a.pre + (size_t)jn[tl] * a.ld_pre + 3 * H;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { ga[tl][t] = ldg4(pi + 16 * t + 4 * g); gb[tl][t] = ldg4(pj + 16 * t + 4 * g); }
-        }
-    };
-    auto hidden = [&](const float *img, auto im_tag, int tl, u32x4 rh, u32x4 rl, u32x4 (&bh)[NT / 2], u32x4 (&bl)[NT / 2]) {
-        using IM = decltype(im_tag);
-        float hid[NT * 4];
-        {
-            f32x4 acc[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = f32x4{ga[tl][t].x + gb[tl][t].x, ga[tl][t].y + gb[tl][t].y, ga[tl][t].z + gb[tl][t].z, ga[tl][t].w + gb[tl][t].w};
-            first_linear16<NT>(reinterpret_cast<const unsigned *>(img) + IM::O_W1, rh, rl, acc, lane);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
-                hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
-            }
-        }
-        ln_relu_dlayout<NT>(hid, img + IM::O_G, img + IM::O_B, g);
-        split_act16<NT>(hid, bh, bl);
-    };
-
-    if (job0 < njobs) { locate(job0, 0); locate(job0, 1); request(0); }       // gathers before the image DMA (see edge16_kernel)
-    dma_to_lds(lds, a.image_k, IMK::TOTAL / 4, wave, nwave, lane);
-    dma_to_lds(lds + V_BASE, a.image_v, IMV::TOTAL / 4, wave, nwave, lane);
-    __syncthreads();
-
-    const float *imk = lds, *imv = lds + V_BASE;
-    const unsigned *w2k = reinterpret_cast<const unsigned *>(imk) + IMK::O_W2;
-    const unsigned *w2v = reinterpret_cast<const unsigned *>(imv) + IMV::O_W2;
-    double *vn_red = reinterpret_cast<double *>(lds + V_BASE + IMV::TOTAL);
-
-    for (int job = job0; job < njobs; job += jstride) {
-        asm volatile("" ::: "memory");   // keep the loop-invariant LDS weight reads inside the loop
-        request(1);                      // tile 1's key rows fly under tile 0's hidden layer (tile 0's were requested a job ahead)
-        float rel[2][3];
-        u32x4 rh[2], rl[2];
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) rel[tl][k] = xi[tl][k] - xj[tl][k];
-            float rb[5];
-            rbf_dlayout(sqrtf(rel[tl][0] * rel[tl][0] + rel[tl][1] * rel[tl][1] + rel[tl][2] * rel[tl][2]), cen, rb);
-            unsigned h, l;
-            rh[tl] = u32x4{0u, 0u, 0u, 0u}; rl[tl] = u32x4{0u, 0u, 0u, 0u};
-            split2_pair(rb[0], rb[1], h, l); rh[tl][0] = h; rl[tl][0] = l;
-            split2_pair(rb[2], rb[3], h, l); rh[tl][1] = h; rl[tl][1] = l;
-            split2_pair(rb[4], 0.f, h, l); rh[tl][2] = h; rl[tl][2] = l;
-        }
-        const int cur_atom[2] = {atom[0], atom[1]};
-        const bool cur_ok[2] = {ok[0], ok[1]}, cur_atom_ok[2] = {atom_ok[0], atom_ok[1]};
-        const float w[2] = {ok[0] ? wgt[0] : 0.f, ok[1] ? wgt[1] : 0.f};
-        // ---- key phase -------------------------------------------------------------------------------------------------
-        float alpha[2][NT / 2];
-        {
-            u32x4 kh[2][NT / 2], kl[2][NT / 2];
-            hidden(imk, IMK{}, 0, rh[0], rl[0], kh[0], kl[0]);
-            hidden(imk, IMK{}, 1, rh[1], rl[1], kh[1], kl[1]);
-            const float *q0 = a.q + (size_t)cur_atom[0] * H + 4 * g, *q1 = a.q + (size_t)cur_atom[1] * H + 4 * g;
-#pragma unroll
-            for (int t = 0; t < NT / 2; ++t) {
-                const float4 qa0 = ldg4(q0 + 16 * t), qb0 = ldg4(q0 + 16 * (t + NT / 2));
-                const float4 qa1 = ldg4(q1 + 16 * t), qb1 = ldg4(q1 + 16 * (t + NT / 2));
-                f32x4 ka0 = {0.f, 0.f, 0.f, 0.f}, ka1 = ka0, kb0 = ka0, kb1 = ka0;
-                tile2_f16x3<NT, NT>(w2k, t, kh[0], kl[0], kh[1], kl[1], ka0, ka1, lane);
-                tile2_f16x3<NT, NT>(w2k, t + NT / 2, kh[0], kl[0], kh[1], kl[1], kb0, kb1, lane);
-                if constexpr (!WIDE) {
-                    alpha[0][t] = attention_weight_pair<NT, SEGW>(qa0, qb0, ka0, kb0, cur_ok[0]);
-                    alpha[1][t] = attention_weight_pair<NT, SEGW>(qa1, qb1, ka1, kb1, cur_ok[1]);
-                } else {
-                    // logits of both tiles (same head pairing as attention_weight_pair), softmax over the 32 slots of the atom
-                    float p[2];
-#pragma unroll
-                    for (int tl = 0; tl < 2; ++tl) {
-                        const float4 qa = tl ? qa1 : qa0, qb = tl ? qb1 : qb0;
-                        const f32x4 ka = tl ? ka1 : ka0, kb = tl ? kb1 : kb0;
-                        float pa = qa.x * ka[0] + qa.y * ka[1] + qa.z * ka[2] + qa.w * ka[3];
-                        float pb = qb.x * kb[0] + qb.y * kb[1] + qb.z * kb[2] + qb.w * kb[3];
-                        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(pa), "+v"(pb));
-                        p[tl] = cur_ok[tl] ? (pa + pb) * 0.35355339059327373f : -INFINITY;
-                    }
-                    const float mx = fmaxf(seg_max<16>(p[0]), seg_max<16>(p[1]));
-                    const float e0 = cur_ok[0] ? fast_exp(p[0] - mx) : 0.f, e1 = cur_ok[1] ? fast_exp(p[1] - mx) : 0.f;
-                    const float s = seg_sum<16>(e0) + seg_sum<16>(e1);
-                    const float inv = s > 0.f ? __builtin_amdgcn_rcpf(s) : 0.f;
-                    alpha[0][t] = e0 * inv; alpha[1][t] = e1 * inv;
-                }
-            }
-        }
-        // ---- value phase (its rows are requested here: with two tiles in flight the register file has no room for them
-        //      during the key MLP's second Linear; the SIMD's other wave covers the latency) ----------------------------
-        {
-            request_v();
-            u32x4 vh[2][NT / 2], vl[2][NT / 2];
-            hidden(imv, IMV{}, 0, rh[0], rl[0], vh[0], vl[0]);
-            hidden(imv, IMV{}, 1, rh[1], rl[1], vh[1], vl[1]);
-            if (job + jstride < njobs) { locate(job + jstride, 0); locate(job + jstride, 1); request(0); }   // next job: tile 0's key rows fly under this second Linear
-            const float *b2 = imv + IMV::O_B2;
-            const bool st0 = cur_atom_ok[0] && (n % SEGW) == 0, st1 = !WIDE && cur_atom_ok[1] && (n % SEGW) == 0;
-            if constexpr (!H2X) {
-                float al[2][NT];
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                    for (int t = 0; t < NT / 2; ++t) {
-                        float lo = alpha[tl][t], hi = alpha[tl][t];
-                        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-                        al[tl][t] = lo * w[tl]; al[tl][t + NT / 2] = hi * w[tl];
-                    }
-                float *op0 = a.out + (size_t)cur_atom[0] * H, *op1 = a.out + (size_t)cur_atom[1] * H;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-                    tile2_f16x3<NT, NT>(w2v, t, vh[0], vl[0], vh[1], vl[1], v0, v1, lane);
-                    const float4 bb = ldg4(b2 + 16 * t + 4 * g);
-                    float o0[4], o1[4];
-                    float sw0 = seg_sum<SEGW>(al[0][t]), sw1 = seg_sum<SEGW>(al[1][t]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { o0[r] = seg_sum<SEGW>(al[0][t] * v0[r]); o1[r] = seg_sum<SEGW>(al[1][t] * v1[r]); }
-                    if constexpr (WIDE) {
-                        sw0 += sw1;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o0[r] += o1[r];
-                    }
-                    if (st0) stg4(op0 + 16 * t + 4 * g, float4{o0[0] + sw0 * bb.x, o0[1] + sw0 * bb.y, o0[2] + sw0 * bb.z, o0[3] + sw0 * bb.w});
-                    if (st1) stg4(op1 + 16 * t + 4 * g, float4{o1[0] + sw1 * bb.x, o1[1] + sw1 * bb.y, o1[2] + sw1 * bb.z, o1[3] + sw1 * bb.w});
-                }
-            } else {
-                const float4 bb = ldg4(b2 + 4 * g);
-                f32x4 va0 = {bb.x, bb.y, bb.z, bb.w}, va1 = va0;
-                tile2_f16x3<NT, 1>(w2v, 0, vh[0], vl[0], vh[1], vl[1], va0, va1, lane);
-                float o[2][12];
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float av = r < NT / 2 ? alpha[tl][r % (NT / 2)] * w[tl] * (tl ? va1[r] : va0[r]) : 0.f;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) o[tl][3 * r + k] = seg_sum<SEGW>(av * rel[tl][k]);
-                    }
-                if constexpr (WIDE) {
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) o[0][i] += o[1][i];
-                }
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
-                    if (tl == 0 ? st0 : st1) {
-                        float *op = a.out + (size_t)cur_atom[tl] * 48 + 12 * g;
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
-                            stg4(op + 4 * i, float4{o[tl][4 * i], o[tl][4 * i + 1], o[tl][4 * i + 2], o[tl][4 * i + 3]});
-                    }
-            }
+// k > 16: merge the two half-atom tiles of every atom.  part [2 N][W] rows (W = H for x2h, 48 for h2x: [16 rows][3] with row
+// 4 g + r belonging to head_of_row), ms [2 N][heads][2] = (max, sum) of each tile's softmax per head.
+struct Combine32Args { const float *part, *ms; float *out; int n_atoms, heads, nt; };
+template <bool H2X>
+__global__ void __launch_bounds__(256) combine32_kernel(Combine32Args a) {
+    const int W = H2X ? 48 : a.heads * 8;
+    const int per = H2X ? 48 : W / 4;                              // items per atom: elements (h2x) or float4 chunks (x2h)
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= a.n_atoms * per) return;
+    const int atom = gid / per, it = gid % per;
+    int head;
+    if constexpr (H2X) {
+        const int m = it / 3, g = m >> 2, r = m & 3;               // value row m = 4 g + r (see pack_image16 / head_of_row)
+        head = r < a.nt / 2 ? 2 * ((a.nt / 2) * (g & 1) + r) + (g >> 1) : -1;
+    } else head = it / 2;                                          // features 4 it .. 4 it + 3 of head (4 it) / 8
+    float c0 = 0.f, c1 = 0.f;
+    if (head >= 0) {
+        const float2 s0 = *reinterpret_cast<const float2 *>(a.ms + ((size_t)(2 * atom) * a.heads + head) * 2);
+        const float2 s1 = *reinterpret_cast<const float2 *>(a.ms + ((size_t)(2 * atom + 1) * a.heads + head) * 2);
+        const float M = fmaxf(s0.x, s1.x);
+        if (M > -INFINITY) {
+            const float w0 = s0.y > 0.f ? s0.y * fast_exp(s0.x - M) : 0.f, w1 = s1.y > 0.f ? s1.y * fast_exp(s1.x - M) : 0.f;
+            const float inv = 1.0f / (w0 + w1);
+            c0 = w0 * inv; c1 = w1 * inv;
         }
     }
-
+    const float *p0 = a.part + (size_t)(2 * atom) * W, *p1 = p0 + W;
     if constexpr (H2X) {
-        if (!a.vn.enable) return;
-        // VN-linear + batch sums of this wave's atoms (see edge16_kernel); the attention rows come back through L2
-        const int v_al = lane >> 4, v_c = lane & 15;
-        const bool v_lane = v_al < APJ && v_c < HD;
-        double v_s1 = 0.0, v_s2 = 0.0;
-        __syncthreads();                             // drain this workgroup's stores first
-        for (int jb = job0; jb < njobs; jb += jstride) {
-            const int va = jb * APJ + v_al;
-            if (v_lane && va < a.n_atoms) {
-                float orow[48];
-                const float *ov = a.out + (size_t)va * 48;
-#pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    const float4 t = ldg4(ov + 4 * i);
-                    orow[4 * i] = t.x; orow[4 * i + 1] = t.y; orow[4 * i + 2] = t.z; orow[4 * i + 3] = t.w;
-                }
-                float wf[16], wd[16];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 t = ldg4(a.vn.wf_o + v_c * 16 + 4 * i), u = ldg4(a.vn.wd_o + v_c * 16 + 4 * i);
-                    wf[4 * i] = t.x; wf[4 * i + 1] = t.y; wf[4 * i + 2] = t.z; wf[4 * i + 3] = t.w;
-                    wd[4 * i] = u.x; wd[4 * i + 1] = u.y; wd[4 * i + 2] = u.z; wd[4 * i + 3] = u.w;
-                }
-                const float *psf = a.vn.ps + ((size_t)a.vn.mol_of[va] * 2 * HD + v_c) * 3;
-                const float *psd = psf + HD * 3;
-                const float wfx = a.vn.wf_x[v_c], wdx = a.vn.wd_x[v_c];
-                float p[3], d[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float xk = a.x[va * 3 + k];
-                    float pp = wfx * xk, dd = wdx * xk;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        pp += wf[r] * orow[r * 3 + k];
-                        dd += wd[r] * orow[r * 3 + k];
-                    }
-                    p[k] = pp + psf[k];
-                    d[k] = dd + psd[k];
-                }
-                float *out = a.vn.pd + ((size_t)va * HD + v_c) * 6;
-                out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
-                const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + 1e-6f;
-                v_s1 += (double)nrm;
-                v_s2 += (double)nrm * (double)nrm;
-            }
-        }
-        vn_red[threadIdx.x * 2] = v_s1; vn_red[threadIdx.x * 2 + 1] = v_s2;      // [wave][lane]
-        __syncthreads();
-        if (threadIdx.x < HD) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int w = 0; w < nwave; ++w)
-                for (int al = 0; al < APJ; ++al) {
-                    s1 += vn_red[(w * 64 + al * 16 + threadIdx.x) * 2];
-                    s2 += vn_red[(w * 64 + al * 16 + threadIdx.x) * 2 + 1];
-                }
-            double *acc = a.vn.acc + (size_t)(blockIdx.x % kVnReplicas) * 2 * HD;
-            atomicAdd(acc + threadIdx.x, s1);
-            atomicAdd(acc + HD + threadIdx.x, s2);
-        }
+        a.out[(size_t)atom * 48 + it] = c0 * p0[it] + c1 * p1[it];
+    } else {
+        const float4 r0 = ldg4(p0 + 4 * it), r1 = ldg4(p1 + 4 * it);
+        stg4(a.out + (size_t)atom * W + 4 * it, float4{c0 * r0.x + c1 * r1.x, c0 * r0.y + c1 * r1.y, c0 * r0.z + c1 * r1.z, c0 * r0.w + c1 * r1.w});
     }
 }

@@ -12,6 +12,7 @@ because these take tens of CPU-minutes while make_golden.py's set regenerates in
     python tests/golden/make_golden_r2.py se        # frozen shape encoder (VN_DGCNN_Encoder), 3 clouds of 512 points
     python tests/golden/make_golden_r2.py loss      # get_diffusion_loss as validate() calls it, module in eval and in train mode
     python tests/golden/make_golden_r2.py all
+    python tests/golden/make_golden_r2.py grad          # round 3: gradients of the training loss (B = 12)
     python tests/golden/make_golden_r2.py retall        # round 3: forward(return_all=True)
     python tests/golden/make_golden_r2.py b256_tail     # round 3: the last 49 steps of the b256 chain in 10-step snapshots (minutes)
     python tests/golden/make_golden_r2.py b1024_s1000   # round 3: configs[2]/[3] per-GPU batch at full length (~3 CPU-hours)
@@ -243,6 +244,52 @@ def loss_fixture():
                         running_stats_seed=23, **rec)
 
 
+def grad_sample_index(key, numel, k=48):
+    """The entries of a parameter's gradient kept in the fixture: k positions drawn by a hash of the key (all of them for
+    tensors of up to 256 entries).  Shared with tests/ (imported from here)."""
+    if numel <= 256:
+        return np.arange(numel)
+    import zlib
+    return np.sort(np.unique(synth.hash_u24(k, zlib.crc32(key.encode()) % 100003, 61) % numel))
+
+
+def grad_fixture():
+    """The training step's backward (scripts/train_diffusion.py:135-147: results['loss'].backward() in train mode): gradients
+    of the loss of diffusion_loss_b12.npz's inputs (train-mode batch-norm) with respect to every parameter.  2.66 M values are
+    not a fixture: per parameter the L2 norm, the sum and a hashed sample of entries (everything for tensors <= 256)."""
+    model, _ = G.load_reference_model()
+    G.synthetic_load(model, seed=7)
+    model.train()
+    f = np.load(os.path.join(HERE, "diffusion_loss_b12.npz"))
+    B, seed = int(f["B"]), int(f["seed"])
+    bb = synth.synthetic_batch(B, seed=seed)
+    n = len(bb["batch"])
+    noise = synth.hash_normal((n, 3), 502, seed)
+    u = synth.hash_uniform((n, 15), 503, seed)
+    with fed_normal([noise]), G.fed_noise(None, [u]), contextlib.redirect_stdout(open(os.devnull, "w")):
+        r = model.get_diffusion_loss(t_(f["pos"]), t_(bb["init_v"]), t_(bb["batch"]), t_(bb["shape"]).view(B, -1), time_step=t_(f["t"]), eval_mode=True)
+    assert abs(float(r["loss"]) - float(f["train_loss"])) < 1e-6 * abs(float(f["train_loss"]))     # the committed forward
+    r["loss"].backward()
+    rec, total = {}, 0.0
+    names = []
+    for k, p in model.named_parameters():
+        names.append(k)
+        if p.grad is None:
+            rec[f"has_{k}"] = False
+            continue
+        g = p.grad.detach().double().numpy().reshape(-1)
+        idx = grad_sample_index(k, g.size)
+        rec[f"has_{k}"] = True
+        rec[f"norm_{k}"] = float(np.sqrt((g * g).sum()))
+        rec[f"sum_{k}"] = float(g.sum())
+        rec[f"val_{k}"] = g[idx].astype(np.float32)
+        total += float((g * g).sum())
+    np.savez_compressed(os.path.join(HERE, "grad_b12.npz"), loss=float(r["loss"]), loss_pos=float(r["loss_pos"]), loss_v=float(r["loss_v"]),
+                        total_grad_norm=float(np.sqrt(total)), names=np.array(names), **rec)
+    print(f"grad: loss {float(r['loss']):.6f}, {len(names)} parameters, {sum(1 for k in names if rec['has_' + k])} with gradients, "
+          f"total norm {np.sqrt(total):.6f}", flush=True)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     # float32 reductions of the CPU BLAS depend on the thread count: every fixture records the count it was made with
@@ -281,6 +328,9 @@ def main():
                             **{f"layer_pos_{i}": x.numpy() for i, x in enumerate(out["layer_pred_ligand_pos"])},
                             **{f"layer_v_{i}": x.numpy() for i, x in enumerate(out["layer_pred_ligand_v"])})
         print("return_all:", len(out["layer_pred_ligand_pos"]), "entries", flush=True)
+    if what in ("grad", "all"):          # round 3: the backward of the training step
+        use_threads("grad")
+        grad_fixture()
     if what in ("se", "all"):
         use_threads("se")
         G.install_stand_ins()

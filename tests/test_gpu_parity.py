@@ -645,7 +645,7 @@ def test_chain_k32_b64_s20_golden():
     assert errs["pos_end"] < POS_TOL and errs["pos_snapshots"] < POS_TOL, errs
 
 
-@pytest.mark.parametrize("tiles", [0, 1, 2])
+@pytest.mark.parametrize("tiles", [0, 1, 2, 3])
 def test_forward_b1024_edge_tile_variants(tiles):
     """The three multi-job forms of the f16 edge kernels at B = 1024: sliced launches of the one-job kernel (default), one
     looping launch with one / two 16-column tiles per wave-job."""
@@ -662,6 +662,32 @@ def test_forward_b1024_edge_tile_variants(tiles):
         m.set_option("edge_tiles", 0)
     for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
         assert maxabs(out[k], ref[k]) < FWD_TOL, k
+
+
+def test_chain_b1024_looping_edge_kernels_equal_sliced_launches():
+    """A short chain at B = 1024 with the looping edge launches (edge_tiles = 1: eight waves per workgroup, consecutive jobs
+    per workgroup, next job's rows prefetched; the coordinate update folded into the next x2h kernel over the workgroup's
+    molecule span) against the sliced one-job launches: same jobs, same arithmetic -- only the order of the float64
+    batch-norm atomics differs."""
+    m = hip_model()
+    B, S = 1024, 6
+    bb = synth.synthetic_batch(B, seed=14, max_atoms=38)
+    eps, u = hash_noise(len(bb["batch"]), S, 14)
+    res = {}
+    try:
+        for tiles in (0, 1):
+            m.set_option("edge_tiles", tiles)
+            for fold in (1, 0):
+                m.set_option("vn_fold", fold)
+                r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
+                res[(tiles, fold)] = (r["pos"].cpu(), r["v"].cpu(), torch.stack(r["pos_cond_traj"]).cpu())
+    finally:
+        m.set_option("edge_tiles", 0)
+        m.set_option("vn_fold", 1)
+    base = res[(0, 1)]
+    for key, (pos, v, cond) in res.items():
+        assert torch.equal(v, base[1]), key
+        assert maxabs(pos, base[0]) < 2e-6 and maxabs(cond, base[2]) < 2e-6, (key, maxabs(pos, base[0]))
 
 
 # ---- point-cloud shape guidance (SURVEY.md section 8 (f3)) ------------------------------------------------------

@@ -184,3 +184,52 @@ def test_chain_b1024_s50_oracle_golden():
     every 10 (the oracle is the cpu_baseline of bench.py --batch 1024 and the checker of test_forward_b1024_vs_oracle)."""
     c = golden("chain_b1024_s50_hash.npz")
     _oracle_chain_against(c, int(c["S"]), max_atoms=38)
+
+
+# ---- the backward of the training step (SURVEY.md section 8 (f4), first milestone) ---------------------------------
+def _grad_sample_index(key, numel, k=48):       # same rule as tests/golden/make_golden_r2.py::grad_sample_index
+    import zlib
+    if numel <= 256:
+        return np.arange(numel)
+    return np.sort(np.unique(synth.hash_u24(k, zlib.crc32(key.encode()) % 100003, 61) % numel))
+
+
+def check_grads_against_fixture(grads, f, rel=1e-4):
+    """grads: {parameter key: float gradient array or None}.  Against tests/golden/grad_b12.npz (the reference's
+    loss.backward()): per parameter the L2 norm and the hashed sample of entries, within `rel` of the parameter's gradient
+    norm (entries) / of the norm itself."""
+    worst = 0.0
+    for key in [str(k) for k in f["names"]]:
+        if not bool(f[f"has_{key}"]):
+            assert grads.get(key) is None or not np.any(grads[key]), key      # dead parameters (never reached by the loss)
+            continue
+        g = np.asarray(grads[key], np.float64).reshape(-1)
+        norm = float(f[f"norm_{key}"])
+        # (gradients that are zero in exact arithmetic -- e.g. the bias of a key MLP's second Linear, which cancels in the
+        # softmax -- are pure rounding noise, 1e-10, in the reference as well: the floor is relative to the whole gradient)
+        scale = max(norm, 1e-5 * float(f["total_grad_norm"]))
+        assert abs(np.sqrt((g * g).sum()) - norm) <= rel * scale, (key, np.sqrt((g * g).sum()), norm)
+        err = np.abs(g[_grad_sample_index(key, g.size)] - f[f"val_{key}"].astype(np.float64)).max()
+        worst = max(worst, err / scale)
+        assert err <= rel * scale, (key, err, norm)
+    return worst
+
+
+def test_diffusion_loss_gradients_oracle_golden():
+    """The differentiable oracle (diffusion_loss(with_grad=True), train-mode batch-norm) against the gradients the reference's
+    own loss.backward() produced for the same inputs: 390 parameter tensors with gradients, 20 without."""
+    f, g = golden("diffusion_loss_b12.npz"), golden("grad_b12.npz")
+    sd, dm, cfg, _ = oracle_model()
+    names = [str(k) for k in g["names"]]
+    # (the schedule tables are registered as frozen parameters in the reference: top-level keys, never differentiated)
+    sd = {k: (v.clone().requires_grad_(True) if (k in names and "." in k) else v) for k, v in sd.items()}
+    bb, noise, u = _loss_inputs(f)
+    r = O.diffusion_loss(sd, dm, T(f["pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(f["t"]), T(noise), T(u), bn_eval=False,
+                         loss_v_weight=cfg["loss_v_weight"], loss_weight_type=cfg["loss_weight_type"], with_grad=True)
+    assert abs(float(r["loss"]) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    r["loss"].backward()
+    grads = {k: (None if sd[k].grad is None else sd[k].grad.numpy()) for k in names}
+    worst = check_grads_against_fixture(grads, g)
+    total = np.sqrt(sum(float((gr.astype(np.float64) ** 2).sum()) for gr in grads.values() if gr is not None))
+    assert abs(total - float(g["total_grad_norm"])) < 1e-4 * float(g["total_grad_norm"]), (total, float(g["total_grad_norm"]))
+    assert worst < 1e-4
