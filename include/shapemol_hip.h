@@ -169,6 +169,24 @@ void shapemol_se_destroy(shapemol_se_ctx *ctx);
 /* d_points (B,N,3) f32 DEVICE, N a multiple of 16; d_out (B,latent_dim,3) f32 DEVICE. */
 int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_shapes, int64_t n_points, float *d_out, void *stream);
 
+/* ---- training building block (first milestone of the backward pass) -----------------------
+ * The MLP block of models/common.py:47-67 -- y = W2 relu(LayerNorm(W1 x + b1)) + b2, eps 1e-5, affine LayerNorm -- forward
+ * with the quantities its backward needs, and the backward: what torch.autograd does for the 58 MLPs of one score
+ * evaluation when scripts/train_diffusion.py:135-147 calls loss.backward().  fp32 arithmetic (fp32 MFMA products), device
+ * pointers, row-major: x (rows,k_in), w1 (hidden,k_in), b1/gamma/beta (hidden), w2 (n_out,hidden), b2 (n_out), y (rows,n_out).
+ * _forward also writes xhat (rows,hidden) = the normalised pre-activation, rstd (rows) and act (rows,hidden) = the ReLU output
+ * (scratch of the call; only xhat and rstd need to be kept for _backward).
+ * _backward: dy (rows,n_out) -> dx (rows,k_in; may be NULL), dw1, db1, dgamma, dbeta, dw2, db2 (OVERWRITTEN, not
+ * accumulated); d_work: shapemol_mlp_backward_workspace() floats.  Reductions over the rows are deterministic. */
+size_t shapemol_mlp_backward_workspace(int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out);
+int shapemol_mlp_forward(const float *d_x, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out, const float *d_w1,
+                         const float *d_b1, const float *d_gamma, const float *d_beta, const float *d_w2, const float *d_b2,
+                         float *d_y, float *d_xhat, float *d_rstd, float *d_act, void *stream);
+int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out,
+                          const float *d_w1, const float *d_gamma, const float *d_beta, const float *d_w2, const float *d_xhat,
+                          const float *d_rstd, float *d_dx, float *d_dw1, float *d_db1, float *d_dgamma, float *d_dbeta,
+                          float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream);
+
 /* ---- diagnostics (used by the parity tests and the bench; not needed by a caller) ---- */
 /* (options marked "_sample only" do not affect _score)
  * options: "first_step" (the following _sample calls resume a chain at reverse step v, i.e. at t = T-1-v, from the
@@ -183,9 +201,10 @@ int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_sh
  *                        0 = the same kernels on exactly split bf16 operands, six products per term),
  *          "lin_bf16", "chain_bf16" (1 = node kernels on the matrix cores with split operands [default],
  *                        0 = fp32-MFMA node kernels),
- *          "edge_tiles" (f16 edge kernels when the waves have several jobs (batches beyond ~6k atoms): 0 = sliced launches
- *                        of the one-job kernel [default], 1 = one looping launch, 2 = one looping launch with two
- *                        16-column tiles per wave-job; k > 16 always uses the two-tile kernel),
+ *          "edge_tiles" (f16 edge kernels when the waves have several jobs (batches beyond ~6k atoms, k > 16): 1 = one looping
+ *                        launch, eight waves per workgroup over consecutive jobs with the next job's rows prefetched,
+ *                        0 = sliced launches of the one-job kernel, -1 = automatic (= 1) [default]; k > 16 runs every atom
+ *                        as two 16-slot tiles merged by an online-softmax combine kernel in either form),
  *          "max_mol_atoms" (_sample only: largest molecule, in atoms, of the batches of the following chains; 0 = unknown [default].  With it
  *                        the coordinate update of every layer but the last runs in the prologue of the next layer's x2h
  *                        kernel (each workgroup recomputes the coordinates of the molecules its atoms belong to) instead

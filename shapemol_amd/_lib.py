@@ -19,6 +19,7 @@ EXPORTS = (
     "shapemol_log_sample_categorical", "shapemol_set_option", "shapemol_debug_read",
     "shapemol_profile_begin", "shapemol_profile_end", "shapemol_status", "shapemol_status_stream", "shapemol_set_guidance", "shapemol_guide_points",
     "shapemol_pointcloud_guidance",
+    "shapemol_mlp_backward_workspace", "shapemol_mlp_forward", "shapemol_mlp_backward",
     "shapemol_set_bn_running",
     "shapemol_se_weight_count", "shapemol_se_create", "shapemol_se_destroy", "shapemol_se_encode",
 )
@@ -87,6 +88,10 @@ def load():
     lib.shapemol_set_guidance.argtypes = [vp, vp, i64, C.c_double, i32, vp]
     lib.shapemol_guide_points.argtypes = [vp, vp, i64, vp, u64, vp]
     lib.shapemol_pointcloud_guidance.argtypes = [vp, i64, C.c_double, C.c_double, vp, i64, vp, u64, vp]
+    lib.shapemol_mlp_backward_workspace.restype = C.c_size_t
+    lib.shapemol_mlp_backward_workspace.argtypes = [i64, i32, i32, i32]
+    lib.shapemol_mlp_forward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.shapemol_mlp_backward.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.shapemol_se_weight_count.restype = C.c_size_t
     lib.shapemol_se_weight_count.argtypes = [i32, i32, i32]
     lib.shapemol_se_create.argtypes = [i32, i32, i32, i32, vp, C.c_size_t, C.c_int, C.POINTER(vp)]

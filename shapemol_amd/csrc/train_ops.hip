@@ -1,0 +1,120 @@
+// C ABI of the training building block (include/shapemol_hip.h, shapemol_mlp_*): forward and backward of the MLP block
+// Linear -> LayerNorm -> ReLU -> Linear (/root/reference/models/common.py:47-67).  Kernels: sm_train.h.
+#include "../../include/shapemol_hip.h"
+#include "sm_train.h"
+
+#include <algorithm>
+#include <string>
+
+extern "C" void shapemol_set_error_(const char *msg);     // shapemol_hip.hip: stores the thread's last error
+
+namespace {
+int tr_fail(const std::string &m) { shapemol_set_error_(m.c_str()); return 1; }
+#define TRCHK(expr)                                                                          \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return tr_fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// C[M][N] = A B (+ bias); see GemmArgs.  splits > 1: partial tiles C + z * M * ldc
+int gemm(hipStream_t s, const float *A, long long sam, long long sak, const float *B, long long sbk, long long sbn, const float *bias,
+         float *C, int ldc, int M, int N, int K, int splits) {
+    if (M < 1 || N < 1 || K < 1) return 0;
+    GemmArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, 0};
+    splits = std::max(1, splits);
+    g.kchunk = ((K + splits - 1) / splits + kGemmKC - 1) / kGemmKC * kGemmKC;
+    const int nz = (K + g.kchunk - 1) / g.kchunk;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, nz), dim3(256), 0, s, g);
+    TRCHK(hipGetLastError());
+    return 0;
+}
+int reduce_parts(hipStream_t s, const float *part, int n_parts, long long n, float *out) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, n_parts, n, out);
+    TRCHK(hipGetLastError());
+    return 0;
+}
+// row-reduction splits of the two weight-gradient products: enough workgroups to fill the chip, at least 256 rows each
+int row_splits(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, rows / 256)); }
+// the number of splits gemm() will really launch for K = rows
+int real_splits(int64_t rows) {
+    const int sp = row_splits(rows);
+    const int64_t kchunk = ((rows + sp - 1) / sp + kGemmKC - 1) / kGemmKC * kGemmKC;
+    return (int)((rows + kchunk - 1) / kchunk);
+}
+bool bad_dims(int64_t rows, int k_in, int hidden, int n_out) {
+    return rows < 1 || rows > (1ll << 26) || k_in < 1 || k_in > 4096 || hidden < 1 || hidden > 1024 || n_out < 1 || n_out > 4096;
+}
+}  // namespace
+
+extern "C" {
+
+size_t shapemol_mlp_backward_workspace(int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out) {
+    if (bad_dims(rows, k_in, hidden, n_out)) return 0;
+    const size_t nwg = (size_t)((rows + kLnRows - 1) / kLnRows), sp = (size_t)real_splits(rows);
+    return 2 * (size_t)rows * hidden                              // activation a (recomputed) | da -> dz
+           + sp * ((size_t)hidden * k_in + (size_t)n_out * hidden)   // split partials of dW1, dW2
+           + nwg * (3 * (size_t)hidden + n_out)                   // partials of dgamma | dbeta, db1, db2
+           + 2 * (size_t)hidden + 64;                             // dgamma | dbeta before they are handed out
+}
+
+int shapemol_mlp_forward(const float *d_x, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out, const float *d_w1,
+                         const float *d_b1, const float *d_gamma, const float *d_beta, const float *d_w2, const float *d_b2,
+                         float *d_y, float *d_xhat, float *d_rstd, float *d_act, void *stream) {
+    if (!d_x || !d_w1 || !d_b1 || !d_gamma || !d_beta || !d_w2 || !d_b2 || !d_y || !d_xhat || !d_rstd || !d_act)
+        return tr_fail("shapemol_mlp_forward: null argument");
+    if (bad_dims(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_forward: dimensions out of range");
+    hipStream_t s = (hipStream_t)stream;
+    // z = x W1^T + b1  (B(k, n) = W1[n][k])
+    if (gemm(s, d_x, k_in, 1, d_w1, 1, k_in, d_b1, d_act, hidden, (int)rows, hidden, k_in, 1)) return 1;
+    hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, d_act, d_gamma, d_beta, d_xhat, d_rstd, (long long)rows, hidden);
+    TRCHK(hipGetLastError());
+    // y = a W2^T + b2
+    return gemm(s, d_act, hidden, 1, d_w2, 1, hidden, d_b2, d_y, n_out, (int)rows, n_out, hidden, 1);
+}
+
+int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out,
+                          const float *d_w1, const float *d_gamma, const float *d_beta, const float *d_w2, const float *d_xhat,
+                          const float *d_rstd, float *d_dx, float *d_dw1, float *d_db1, float *d_dgamma, float *d_dbeta,
+                          float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream) {
+    if (!d_x || !d_dy || !d_w1 || !d_gamma || !d_beta || !d_w2 || !d_xhat || !d_rstd || !d_dw1 || !d_db1 || !d_dgamma || !d_dbeta ||
+        !d_dw2 || !d_db2 || !d_work)
+        return tr_fail("shapemol_mlp_backward: null argument (only d_dx may be NULL)");
+    if (bad_dims(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_backward: dimensions out of range");
+    if (work_floats < shapemol_mlp_backward_workspace(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_backward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int R = (int)rows, H = hidden;
+    const int nwg = (int)((rows + kLnRows - 1) / kLnRows), sp = row_splits(rows), spr = real_splits(rows);
+    float *act = d_work, *dz = act + (size_t)rows * H, *pw1 = dz + (size_t)rows * H, *pw2 = pw1 + (size_t)spr * H * k_in,
+          *pln = pw2 + (size_t)spr * n_out * H, *pb1 = pln + (size_t)nwg * 2 * H, *pb2 = pb1 + (size_t)nwg * H,
+          *gb = pb2 + (size_t)nwg * n_out;
+    // da = dy W2  (A = dy [R][O], B(k, n) = W2[k][n])
+    if (gemm(s, d_dy, n_out, 1, d_w2, H, 1, nullptr, dz, H, R, H, n_out, 1)) return 1;
+    // db2 partials (column sums of dy)
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nwg), dim3(256), 0, s, d_dy, (long long)rows, n_out, pb2);
+    TRCHK(hipGetLastError());
+    if (reduce_parts(s, pb2, nwg, n_out, d_db2)) return 1;
+    // the activation a = relu(xhat * gamma + beta), recomputed (one elementwise pass instead of a second saved [rows][H] array
+    // per MLP), for dW2 = dy^T a:  A(m, k) = dy[k][m], B(k, n) = a[k][n], reduction over the rows in splits
+    hipLaunchKernelGGL(relu_affine_kernel, dim3((unsigned)(((long long)rows * H + 255) / 256)), dim3(256), 0, s, d_xhat, d_gamma, d_beta, act, (long long)rows, H);
+    TRCHK(hipGetLastError());
+    if (gemm(s, d_dy, 1, n_out, act, H, 1, nullptr, pw2, H, n_out, H, R, sp)) return 1;
+    if (reduce_parts(s, pw2, spr, (long long)n_out * H, d_dw2)) return 1;
+    // LayerNorm + ReLU backward: da -> dz in place, dgamma | dbeta partials
+    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nwg), dim3(256), (size_t)4 * 2 * H * sizeof(float), s, dz, d_xhat, d_rstd, d_gamma, d_beta, (long long)rows, H, pln);
+    TRCHK(hipGetLastError());
+    if (reduce_parts(s, pln, nwg, 2 * H, gb)) return 1;
+    TRCHK(hipMemcpyAsync(d_dgamma, gb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TRCHK(hipMemcpyAsync(d_dbeta, gb + H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // db1 = column sums of dz
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nwg), dim3(256), 0, s, dz, (long long)rows, H, pb1);
+    TRCHK(hipGetLastError());
+    if (reduce_parts(s, pb1, nwg, H, d_db1)) return 1;
+    // dW1 = dz^T x:  A(m, k) = dz[k][m], B(k, n) = x[k][n]
+    if (gemm(s, dz, 1, H, d_x, k_in, 1, nullptr, pw1, k_in, H, k_in, R, sp)) return 1;
+    if (reduce_parts(s, pw1, spr, (long long)H * k_in, d_dw1)) return 1;
+    // dx = dz W1  (B(k, n) = W1[k][n])
+    if (d_dx && gemm(s, dz, H, 1, d_w1, k_in, 1, nullptr, d_dx, k_in, R, k_in, H, 1)) return 1;
+    return 0;
+}
+
+}  // extern "C"

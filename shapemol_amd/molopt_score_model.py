@@ -286,16 +286,16 @@ class ScorePosNet3D(nn.Module):
                            noise=None):
         """The reference's loss evaluation (models/molopt_score_model.py:447-531): perturb positions and atom types at
         ``time_step`` (sampled symmetrically if None), one score evaluation on the device, position MSE and atom-type KL
-        per molecule.  Same arguments and result dict.  This is the form validate() runs (scripts/train_diffusion.py:168-192,
-        under torch.no_grad() with the module in eval mode, which switches the batch-norm to its running statistics);
-        gradients are NOT available on this path -- a call with autograd enabled raises instead of returning a loss that
-        cannot be back-propagated.
+        per molecule.  Same arguments and result dict.  Under torch.no_grad() -- the form validate() runs
+        (scripts/train_diffusion.py:168-192, module in eval mode, which switches the batch-norm to its running statistics) --
+        the score evaluation is the HIP sampling path.  With autograd enabled -- the training step,
+        scripts/train_diffusion.py:135-147 -- it is the differentiable evaluation of shapemol_amd.training (every MLP block
+        forward and backward in HIP, the glue in torch device ops; first milestone of the backward pass), so that
+        ``result['loss'].backward()`` fills ``.grad`` of every parameter (gate: tests/golden/grad_b12.npz, the reference's own
+        gradients).
 
         Extension (keyword-only): ``noise=(pos_noise (N,3), u (N,C))`` feeds the normal draw of :461 and the uniforms of
         log_sample_categorical (:98-104, inside q_v_sample :366-374) instead of torch's generator (parity tests)."""
-        if torch.is_grad_enabled():
-            raise NotImplementedError("shapemol_amd evaluates the diffusion loss without gradients (validation); wrap the call "
-                                      "in torch.no_grad() -- the training step (backward) is not part of the accelerated path")
         if self.v_mode != "uniform":
             raise NotImplementedError("v_mode = 'uniform' only (the shipped training configuration)")
         pos = _check_device_tensor("ligand_pos", ligand_pos, torch.float32)
@@ -324,7 +324,11 @@ class ScorePosNet3D(nn.Module):
         if not eval_mode:       # classifier-free condition masking (:480-484; cond_mask_prob = 0 in the shipped configuration)
             keep = torch.bernoulli(torch.ones(num_graphs) * (1 - (self.cond_mask_prob or 0.0))).to(shape.device)
             shape = keep.view(-1, 1, 1) * shape
-        preds = self(pos_pert, v_pert, batch, shape, time_step=t)
+        if torch.is_grad_enabled():
+            from .training import score_with_grad
+            preds = score_with_grad(self, pos_pert, v_pert, batch, shape, t)
+        else:
+            preds = self(pos_pert, v_pert, batch, shape, time_step=t)
         pred_pos, pred_v = preds["pred_ligand_pos"], preds["pred_ligand_v"]
         # atom types: KL between the true and the model posterior, decoder NLL at t = 0
         log_recon = torch.nn.functional.log_softmax(pred_v, dim=-1)

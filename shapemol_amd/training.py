@@ -1,0 +1,206 @@
+"""Training step on the device (first milestone of the backward pass).
+
+What the reference's ``scripts/train_diffusion.py:135-147`` needs from the model is ``get_diffusion_loss(...)['loss']``
+with autograd recording, so that ``loss.backward()`` fills ``.grad`` of every parameter.  The sampling path of this package
+is hand-written HIP without a backward; this module is the differentiable evaluation of the same network for the
+training step:
+
+  * every MLP block (``models/common.py:47-67``: Linear -> LayerNorm -> ReLU -> Linear; 58 of them per evaluation, ~95 % of
+    the FLOPs of forward and backward) is ONE autograd node, :class:`HipMLP`, whose forward and backward are the HIP
+    kernels of ``csrc/sm_train.h`` (fp32 MFMA products, deterministic reductions) behind ``shapemol_mlp_forward`` /
+    ``shapemol_mlp_backward`` of the C ABI;
+  * the glue between them -- neighbour gathers, the segment softmax of the attention, scatter sums, the vector-neuron
+    linear / batch-norm / leaky-ReLU of the coordinate update, the two small Linears of the time embedding and of the
+    atom-type head -- is torch device ops recorded by autograd (the next milestones move them into HIP kernels with
+    hand-written backwards; the gate for each is ``tests/golden/grad_b12.npz``, the reference's own gradients).
+
+Reference semantics followed: ``models/molopt_score_model.py:286-320`` (forward), ``models/uni_transformer.py:48-90,
+121-162,181-189,446-540`` (layers, graph, shape embedding), ``models/shape_vn_layers.py:41-61,95-110`` (VN batch-norm in
+train mode, running statistics updated with momentum 0.1 as ``nn.BatchNorm1d`` does), ``models/common.py:19-28,39-45``.
+There is no CPU path here either: tensors must live on a HIP device.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .spec import RBF_CENTRES
+
+VN_EPS = 1e-6
+LEAK = 0.2
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class HipMLP(torch.autograd.Function):
+    """y = W2 relu(LayerNorm(W1 x + b1)) + b2 on rows of x; forward and backward are HIP kernels (csrc/sm_train.h)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, gamma, beta, w2, b2):
+        if not x.is_cuda:
+            raise RuntimeError("HipMLP needs tensors on a HIP device (shapemol_amd has no CPU path)")
+        x = x.contiguous().float()
+        ws = [t.detach().contiguous().float() for t in (w1, b1, gamma, beta, w2, b2)]
+        rows, k_in = x.shape
+        hidden, n_out = ws[0].shape[0], ws[4].shape[0]
+        y = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+        xhat = torch.empty((rows, hidden), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        act = torch.empty((rows, hidden), dtype=torch.float32, device=x.device)
+        if rows > 0:
+            with torch.cuda.device(x.device):
+                rc = _lib.load().shapemol_mlp_forward(_p(x), rows, k_in, hidden, n_out, _p(ws[0]), _p(ws[1]), _p(ws[2]), _p(ws[3]),
+                                                      _p(ws[4]), _p(ws[5]), _p(y), _p(xhat), _p(rstd), _p(act),
+                                                      C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            _lib.check(rc, "shapemol_mlp_forward")
+        ctx.save_for_backward(x, ws[0], ws[2], ws[3], ws[4], xhat, rstd)
+        ctx.dims = (rows, k_in, hidden, n_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, gamma, beta, w2, xhat, rstd = ctx.saved_tensors
+        rows, k_in, hidden, n_out = ctx.dims
+        dev = x.device
+        dy = dy.contiguous().float()
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
+        dx, dw1, db1, dg, dbe, dw2, db2 = z(rows, k_in), z(hidden, k_in), z(hidden), z(hidden), z(hidden), z(n_out, hidden), z(n_out)
+        if rows > 0:
+            lib = _lib.load()
+            n_work = lib.shapemol_mlp_backward_workspace(rows, k_in, hidden, n_out)
+            work = torch.empty((n_work,), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.shapemol_mlp_backward(_p(x), _p(dy), rows, k_in, hidden, n_out, _p(w1), _p(gamma), _p(beta), _p(w2), _p(xhat),
+                                               _p(rstd), _p(dx) if ctx.needs_input_grad[0] else None, _p(dw1), _p(db1), _p(dg), _p(dbe),
+                                               _p(dw2), _p(db2), _p(work), n_work, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(rc, "shapemol_mlp_backward")
+        return (dx if ctx.needs_input_grad[0] else None), dw1, db1, dg, dbe, dw2, db2
+
+
+def _mlp(P, prefix, x):
+    return HipMLP.apply(x, P[prefix + ".net.0.weight"], P[prefix + ".net.0.bias"], P[prefix + ".net.1.weight"], P[prefix + ".net.1.bias"],
+                        P[prefix + ".net.3.weight"], P[prefix + ".net.3.bias"])
+
+
+def _rbf(d):
+    """Gaussian smearing with the reference's 20 fixed centres, coeff = -0.5 (models/common.py:19-28)."""
+    mu = torch.tensor(RBF_CENTRES, dtype=torch.float32, device=d.device)
+    return torch.exp(-0.5 * (d.view(-1, 1) - mu.view(1, -1)) ** 2)
+
+
+def knn_edges(x, batch, k):
+    """Per-molecule k nearest neighbours on the device (self excluded; ties by (squared distance, index), the squared
+    distance evaluated as (dx*dx + dy*dy) + dz*dz like the sampling kernels): (src = j, dst = i), grouped by centre i."""
+    n = x.shape[0]
+    counts = torch.bincount(batch)
+    B, M = counts.shape[0], int(counts.max())
+    first = torch.cumsum(counts, 0) - counts
+    local = torch.arange(n, device=x.device) - first[batch]
+    pad = torch.zeros((B, M, 3), dtype=x.dtype, device=x.device)
+    pad[batch, local] = x.detach()
+    valid = torch.zeros((B, M), dtype=torch.bool, device=x.device)
+    valid[batch, local] = True
+    d = pad[:, :, None, :] - pad[:, None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    inf = torch.tensor(float("inf"), device=x.device)
+    d2 = torch.where(valid[:, None, :] & valid[:, :, None], d2, inf)
+    d2 = torch.where(torch.eye(M, dtype=torch.bool, device=x.device)[None], inf, d2)
+    order = torch.sort(d2, dim=2, stable=True)[1][:, :, :min(k, M)]             # (B, M, k) local neighbour indices
+    rank = torch.arange(order.shape[2], device=x.device)
+    has = valid[:, :, None] & (rank[None, None, :] < (counts - 1).clamp(max=k)[:, None, None])
+    src = (order + first[:, None, None])[has]
+    dst = (torch.arange(M, device=x.device)[None, :, None] + first[:, None, None]).expand_as(order)[has]
+    return src, dst
+
+
+def _segment_softmax(logit, dst, n):
+    idx = dst.view(-1, 1).expand_as(logit)
+    mx = torch.full((n, logit.shape[1]), float("-inf"), device=logit.device).scatter_reduce(0, idx, logit.detach(), "amax", include_self=True)
+    ex = torch.exp(logit - mx[dst])
+    den = torch.zeros((n, logit.shape[1]), device=logit.device).index_add(0, dst, ex)
+    return ex / den[dst]
+
+
+def _segment_sum(val, dst, n):
+    return torch.zeros((n,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device).index_add(0, dst, val)
+
+
+def _attention(q, k, dst, n, heads):
+    dh = q.shape[1] // heads
+    logit = (q[dst].view(-1, heads, dh) * k.view(-1, heads, dh) / math.sqrt(dh)).sum(-1)
+    return _segment_softmax(logit, dst, n)
+
+
+def _vn_linear_lrelu(P, B, p, z, training):
+    """VNLinearLeakyReLU with VNBatchNorm (models/shape_vn_layers.py:41-61,95-110); z (N, Cin, 3) -> (N, Cout, 3)."""
+    wf, wd = P[p + ".map_to_feat.weight"], P[p + ".map_to_dir.weight"]
+    pf = torch.einsum("oc,ncd->nod", wf, z)
+    nrm = torch.sqrt((pf * pf).sum(2)) + VN_EPS
+    rm, rv = B[p + ".batchnorm.bn.running_mean"], B[p + ".batchnorm.bn.running_var"]
+    if training:
+        mean = nrm.mean(0)
+        var = ((nrm - mean) ** 2).mean(0)
+        with torch.no_grad():      # nn.BatchNorm1d in train mode: momentum 0.1, unbiased variance into the running estimate
+            cnt = nrm.shape[0]
+            rm.mul_(0.9).add_(0.1 * mean.detach())
+            rv.mul_(0.9).add_(0.1 * var.detach() * (cnt / max(cnt - 1, 1)))
+            B[p + ".batchnorm.bn.num_batches_tracked"].add_(1)
+    else:
+        mean, var = rm, rv
+    nbn = (nrm - mean) / torch.sqrt(var + 1e-5) * P[p + ".batchnorm.bn.weight"] + P[p + ".batchnorm.bn.bias"]
+    pf = pf / nrm.unsqueeze(2) * nbn.unsqueeze(2)
+    d = torch.einsum("oc,ncd->nod", wd, z)
+    dot = (pf * d).sum(2, keepdim=True)
+    mask = (dot >= 0).float()
+    dsq = (d * d).sum(2, keepdim=True)
+    return LEAK * pf + (1 - LEAK) * (mask * pf + (1 - mask) * (pf - (dot / (dsq + VN_EPS)) * d))
+
+
+def score_with_grad(model, pos, v, batch, shape, t):
+    """One score evaluation recorded by autograd; same result dict as ``ScorePosNet3D.forward``."""
+    dm = model.dims
+    P = dict(model.named_parameters())
+    Bf = dict(model.named_buffers())
+    lin = lambda p, x: F.linear(x, P[p + ".weight"], P[p + ".bias"])  # noqa: E731
+    n = pos.shape[0]
+    # time embedding (molopt_score_model.py:154-166,247-252) and atom embedding (:292-301)
+    half = dm.temb // 2
+    freq = torch.exp(torch.arange(half, device=pos.device, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    arg = t[:, None].float() * freq[None, :]
+    temb = lin("time_emb.3", F.silu(lin("time_emb.1", torch.cat((arg.sin(), arg.cos()), dim=-1))))
+    h = lin("ligand_atom_emb", torch.cat([F.one_hot(v, dm.C).float(), temb[batch]], -1))
+    # invariant shape embedding (uni_transformer.py:181-189), graph, edge weights (:446-481)
+    shape = shape.view(-1, dm.S, 3)
+    m = shape.mean(dim=1)
+    m = m / ((m * m).sum(-1, keepdim=True) + VN_EPS)
+    inv_atom = _mlp(P, "refine_net.invariant_shape_layer.hidden_layer", torch.einsum("bij,bj->bi", shape, m))[batch]
+    shape_atom = shape[batch]
+    x = pos
+    src, dst = knn_edges(x, batch, dm.k)
+    e_w = torch.sigmoid(_mlp(P, "refine_net.edge_pred_layer", _rbf(torch.norm(x[dst] - x[src], p=2, dim=-1))))
+    dh = dm.H // dm.heads
+    for l in range(dm.L):
+        p = f"refine_net.base_block.{l}"
+        rel_x = x[dst] - x[src]
+        rfeat = _rbf(torch.norm(rel_x, p=2, dim=-1))
+        # x2h (uni_transformer.py:48-90)
+        px = p + ".x2h_layers.0"
+        kv = torch.cat([rfeat, h[dst], h[src], inv_atom[dst]], -1)
+        alpha = _attention(_mlp(P, px + ".hq_func", h), _mlp(P, px + ".hk_func", kv), dst, n, dm.heads)
+        val = (_mlp(P, px + ".hv_func", kv) * e_w.view(-1, 1)).view(-1, dm.heads, dh)
+        o = _segment_sum(alpha.unsqueeze(-1) * val, dst, n).view(n, dm.H)
+        h = _mlp(P, px + ".node_output", torch.cat([o, h], -1)) + h
+        # h2x (uni_transformer.py:121-162)
+        ph = p + ".h2x_layers.0"
+        kv = torch.cat([rfeat, h[dst], h[src], inv_atom[dst]], -1)
+        alpha = _attention(_mlp(P, ph + ".xq_func", h), _mlp(P, ph + ".xk_func", kv), dst, n, dm.heads)
+        val = (_mlp(P, ph + ".xv_func", kv) * e_w.view(-1, 1)).unsqueeze(-1) * rel_x.unsqueeze(1)
+        o3 = _segment_sum(alpha.unsqueeze(-1) * val, dst, n)                         # (N, heads, 3)
+        z = torch.cat((x.unsqueeze(1), o3, shape_atom), dim=1)
+        x = x + o3.mean(dim=1) + _vn_linear_lrelu(P, Bf, ph + ".shape_linear", z, model.training).mean(dim=1)
+    hv = F.softplus(lin("v_inference.0", h)) - math.log(2.0)
+    return {"pred_ligand_pos": x, "pred_ligand_h": h, "pred_ligand_v": lin("v_inference.2", hv)}

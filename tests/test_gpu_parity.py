@@ -645,10 +645,10 @@ def test_chain_k32_b64_s20_golden():
     assert errs["pos_end"] < POS_TOL and errs["pos_snapshots"] < POS_TOL, errs
 
 
-@pytest.mark.parametrize("tiles", [0, 1, 2, 3])
+@pytest.mark.parametrize("tiles", [-1, 0, 1])
 def test_forward_b1024_edge_tile_variants(tiles):
-    """The three multi-job forms of the f16 edge kernels at B = 1024: sliced launches of the one-job kernel (default), one
-    looping launch with one / two 16-column tiles per wave-job."""
+    """The multi-job forms of the f16 edge kernels at B = 1024: the looping launch (eight waves per workgroup; the default, -1 =
+    automatic) and sliced launches of the one-job kernel."""
     m = hip_model()
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(1024, seed=14, max_atoms=38)
@@ -659,7 +659,7 @@ def test_forward_b1024_edge_tile_variants(tiles):
         with torch.no_grad():
             out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
     finally:
-        m.set_option("edge_tiles", 0)
+        m.set_option("edge_tiles", -1)
     for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
         assert maxabs(out[k], ref[k]) < FWD_TOL, k
 
@@ -682,7 +682,7 @@ def test_chain_b1024_looping_edge_kernels_equal_sliced_launches():
                 r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
                 res[(tiles, fold)] = (r["pos"].cpu(), r["v"].cpu(), torch.stack(r["pos_cond_traj"]).cpu())
     finally:
-        m.set_option("edge_tiles", 0)
+        m.set_option("edge_tiles", -1)
         m.set_option("vn_fold", 1)
     base = res[(0, 1)]
     for key, (pos, v, cond) in res.items():
@@ -936,8 +936,6 @@ def test_diffusion_loss_golden(mode):
     n = len(bb["batch"])
     noise, u = synth.hash_normal((n, 3), 502, seed), synth.hash_uniform((n, 15), 503, seed)
     args = (T(f["pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV).view(B, -1))
-    with pytest.raises(NotImplementedError, match="without gradients"):
-        m.get_diffusion_loss(*args, time_step=T(f["t"], DEV), eval_mode=True)
     with torch.no_grad():
         r = m.get_diffusion_loss(*args, time_step=T(f["t"], DEV), eval_mode=True, noise=(T(noise, DEV), T(u, DEV)))
     m.check_status()
@@ -1038,3 +1036,70 @@ def test_rccl_single_rank_gather_of_device_tensors():
         assert torch.equal(p2.view(torch.int32), odd.view(torch.int32))
     finally:
         dist.destroy_process_group()
+
+
+# ---- training step: backward (first milestone) ---------------------------------------------
+@pytest.mark.parametrize("rows,k_in,hidden,n_out", [(77, 308, 128, 128), (1000, 308, 128, 16), (5, 20, 128, 1), (33, 32, 32, 32), (1, 256, 128, 128)])
+def test_hip_mlp_forward_backward_vs_torch_autograd(rows, k_in, hidden, n_out):
+    """HipMLP (csrc/sm_train.h: fp32 MFMA products, deterministic reductions) against torch autograd of the same block in
+    float64 on the device: outputs and all seven gradients, relative to each tensor's largest entry."""
+    from shapemol_amd.training import HipMLP
+    g = torch.Generator().manual_seed(rows * 7 + n_out)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)  # noqa: E731
+    x = mk(rows, k_in)
+    ws = [mk(hidden, k_in, sc=k_in ** -0.5), mk(hidden, sc=0.3), 1 + mk(hidden, sc=0.2), mk(hidden, sc=0.3), mk(n_out, hidden, sc=hidden ** -0.5), mk(n_out, sc=0.3)]
+    dy = mk(rows, n_out)
+    a = [t.clone().requires_grad_(True) for t in [x] + ws]
+    y = HipMLP.apply(*a)
+    y.backward(dy)
+    b = [t.double().clone().requires_grad_(True) for t in [x] + ws]
+    z = torch.nn.functional.linear(b[0], b[1], b[2])
+    hh = torch.relu(torch.nn.functional.layer_norm(z, (hidden,), b[3], b[4], 1e-5))
+    yr = torch.nn.functional.linear(hh, b[5], b[6])
+    yr.backward(dy.double())
+    rel = lambda p, q: float((p.double() - q).abs().max() / q.abs().max().clamp(min=1e-6))  # noqa: E731
+    assert rel(y, yr) < 1e-5
+    names = ["dx", "dW1", "db1", "dgamma", "dbeta", "dW2", "db2"]
+    errs = {nm: rel(p.grad, q.grad) for nm, p, q in zip(names, a, b)}
+    assert max(errs.values()) < 1e-4, errs
+    y2 = HipMLP.apply(*[t.detach().clone().requires_grad_(True) for t in [x] + ws])      # deterministic: bit-identical on a second run
+    assert torch.equal(y2, y)
+
+
+def test_training_step_gradients_golden():
+    """get_diffusion_loss with autograd enabled (the training step, scripts/train_diffusion.py:135-147) on the device: loss and
+    the gradients of all 390 differentiated parameter tensors against the reference's own loss.backward() (grad_b12.npz),
+    1e-4 of each tensor's gradient norm; train-mode batch-norm, running statistics updated as nn.BatchNorm1d does."""
+    import shapemol_amd
+    from util import model_cfg, record
+    from test_oracle_golden import check_grads_against_fixture
+    f, g = golden("diffusion_loss_b12.npz"), golden("grad_b12.npz")
+    cfg = model_cfg()
+    m = shapemol_amd.ScorePosNet3D(cfg, 15)
+    sdn = synth.synthetic_state_dict(cfg, seed=7)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
+    m = m.to(DEV).train()
+    B, seed = int(f["B"]), int(f["seed"])
+    bb = synth.synthetic_batch(B, seed=seed)
+    n = len(bb["batch"])
+    noise, u = synth.hash_normal((n, 3), 502, seed), synth.hash_uniform((n, 15), 503, seed)
+    r = m.get_diffusion_loss(T(f["pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV).view(B, -1),
+                             time_step=T(f["t"], DEV), eval_mode=True, noise=(T(noise, DEV), T(u, DEV)))
+    assert abs(float(r["loss"]) - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    assert maxabs(r["pred_ligand_pos"].detach(), f["train_pred_ligand_pos"]) < FWD_TOL
+    r["loss"].backward()
+    grads = {k: (None if p.grad is None else p.grad.detach().cpu().numpy()) for k, p in m.named_parameters()}
+    worst = check_grads_against_fixture(grads, g)
+    total = np.sqrt(sum(float((gr.astype(np.float64) ** 2).sum()) for gr in grads.values() if gr is not None))
+    record("training_step_gradients_golden", loss=float(r["loss"]), worst_rel_to_tensor_norm=worst, total_grad_norm=total)
+    assert abs(total - float(g["total_grad_norm"])) < 1e-4 * float(g["total_grad_norm"])
+    # the batch-norm running statistics moved (train mode), and one optimiser step on these gradients lowers the loss
+    rm = dict(m.named_buffers())["refine_net.base_block.0.h2x_layers.0.shape_linear.batchnorm.bn.running_mean"]
+    assert float(rm.abs().max()) > 0
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.grad is not None:
+                p.add_(p.grad, alpha=-1e-4)
+    r2 = m.get_diffusion_loss(T(f["pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV).view(B, -1),
+                              time_step=T(f["t"], DEV), eval_mode=True, noise=(T(noise, DEV), T(u, DEV)))
+    assert float(r2["loss"]) < float(r["loss"])
