@@ -39,7 +39,7 @@ TRAIN_YML = os.path.join(ROOT, "config", "training",
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0      # dense f16 / bf16 matrix peak (same guide)
 HBM_PEAK_GBS = 8000.0              # HBM3E peak (same guide)
-PROFILE_DIR = "r02_final"          # profiles/<dir>/pmc_traffic*.json hold the PMC traffic of the kernels timed here
+PROFILE_DIR = "r03"          # profiles/<dir>/pmc_traffic*.json hold the PMC traffic of the kernels timed here
 CHAIN_STEPS = 1000                 # the metric is quoted for 1000-step chains
 # what the arithmetic is: fp32 inputs, outputs, accumulators and vector work; the matrix products take their fp32 operands as
 # two f16 pieces each (hi + lo, 22 significand bits) and sum three piece products in fp32.  `exact_mode` on the JSON line times
@@ -61,11 +61,14 @@ def reference_flops_per_atom_step(k, L=8):
     return L * (k * 417792 + 238784) + k * 5376 + 42496
 
 
-def cpu_baseline(cfg, batch, n_steps):
+CPU_THREADS_DEFAULT = 16           # tools/cpu_baseline_sweep.py (profiles/r03/cpu_baseline_sweep.json): the fastest of 8 / 16 / 32 / 64 on the GPU box
+
+
+def cpu_baseline(cfg, batch, n_steps, threads=0):
     """The CPU oracle on the same workload, timed on this host (bounded sample)."""
     from oracle import shapemol_oracle as O
     # the box's CPU share (16 cores per GPU) is smaller than os.cpu_count(): oversubscribing OpenMP stalls the run
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)), 16)))
+    torch.set_num_threads(threads if threads > 0 else max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)), CPU_THREADS_DEFAULT)))
     sd = O.state_dict_from_numpy(synth.synthetic_state_dict(cfg, seed=7))
     dm = O.Dims(cfg)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
@@ -98,6 +101,7 @@ def main():
                          "through its packing / all_gather_into_tensor / unpacking path (exercises the RCCL branch on a one-GPU box)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--cpu-steps", type=int, default=20, help="reverse steps of the CPU oracle to time (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle (0 = the measured best, see CPU_THREADS_DEFAULT)")
     ap.add_argument("--exact-steps", type=int, default=-1, help="reverse steps of the exact-operand chain (extra field `exact_mode`; "
                                                                 "-1 = as --steps, 0 = skip)")
     ap.add_argument("--no-traj", action="store_true", help="do not keep per-step trajectories")
@@ -335,7 +339,7 @@ def main():
         # ---- CPU baseline: the oracle on this host, bounded sample ---------------------------
         if world == 1 and args.cpu_steps > 0:
             log(f"CPU oracle baseline: {args.cpu_steps} steps")
-            dt, cores = cpu_baseline(cfg, bb, args.cpu_steps)
+            dt, cores = cpu_baseline(cfg, bb, args.cpu_steps, args.cpu_threads)
             out["cpu_baseline"] = {"value": round(args.batch / (CHAIN_STEPS * dt), 4), "unit": "molecules/s", "cores": cores,
                                    "os_cpu_count": os.cpu_count(), "cpu_affinity": len(os.sched_getaffinity(0)),
                                    "kind": "port", "sample": f"{args.cpu_steps} reverse steps of the same B={args.batch} batch "

@@ -641,7 +641,7 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
-    if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) } else { SETATTR(32) SETATTR6(32) }
+    if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) } else { SETATTR6(32) }
 #undef SETATTR6
 #undef SETATTR4
 #undef SETATTR3
@@ -667,7 +667,7 @@ int launch_edge(shapemol_ctx *c, hipStream_t s, const EdgeArgs &a) {     // fp32
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
     if (KP == 8) LAUNCH(nm, SMK((edge_attention_kernel<H, 8, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
     else if (KP == 16) LAUNCH(nm, SMK((edge_attention_kernel<H, 16, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
-    else LAUNCH(nm, SMK((edge_attention_kernel<H, 32, H2X>), dim3(grid), dim3(waves * 64), shm, s, a));
+    else return fail("k > 16 runs on the two-piece f16 edge kernels only (option edge_bf16 = 3)");
     return 0;
 }
 
@@ -1138,7 +1138,10 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
         hipLaunchKernelGGL(emb_table_kernel, dim3((items + 255) / 256), dim3(256), 0, nullptr, c->P(dm.embwT), c->P(dm.embb), c->ttab, c->etab, T, C, cfg->time_emb_dim, H);
         if (hipDeviceSynchronize() != hipSuccess) { hipFree(c->etab); hipFree(c->ttab); hipFree(c->d_img); delete c; return fail("embedding table kernel failed"); }
     }
-    if (c->hid_max > 6.0e4f) c->edge_bf16 = 1;      // hidden activations could overflow fp16: exactly split bf16 kernels
+    if (c->hid_max > 6.0e4f) {      // hidden activations could overflow fp16: exactly split bf16 kernels (k <= 16 only)
+        if (c->KP > 16) { shapemol_destroy(c); return fail("shapemol_create: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights, and k > 16 has no bf16 path"); }
+        c->edge_bf16 = 1;
+    }
     *out = c;
     return 0;
 }
@@ -1298,6 +1301,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     if (k == "stop_layer") c->stop_layer = (int)value;
     else if (k == "edge_bf16") {
         if (value != 0 && value != 1 && value != 3) return fail("edge_bf16 must be 0 (fp32 MFMA), 1 (exactly split bf16) or 3 (two-piece f16)");
+        if (value != 3 && c->KP > 16) return fail("k > 16 runs on the two-piece f16 edge kernels only (edge_bf16 = 3)");
         if (value == 3 && c->hid_max > 6.0e4f) return fail("edge_bf16 = 3: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights");
         c->edge_bf16 = (int)value;
     }

@@ -88,9 +88,9 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float *part, int n_parts, long long n, float *out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < n_parts; ++p) s += part[(size_t)p * n + i];
-    out[i] = s;
+    double s = 0.0;                 // (partials of sums that cancel -- a bias in front of a LayerNorm -- are added in float64)
+    for (int p = 0; p < n_parts; ++p) s += (double)part[(size_t)p * n + i];
+    out[i] = (float)s;
 }
 
 // LayerNorm + ReLU of the rows of z [rows][H] (in place: z becomes the activation a), keeping xhat and rstd for the backward.
@@ -163,8 +163,8 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float *x, lon
     const long long r0 = (long long)blockIdx.x * kLnRows;
     const long long r1 = r0 + kLnRows < rows ? r0 + kLnRows : rows;
     for (int c = threadIdx.x; c < cols; c += 256) {
-        float s = 0.f;
-        for (long long r = r0; r < r1; ++r) s += x[r * cols + c];
-        part[(size_t)blockIdx.x * cols + c] = s;
+        double s = 0.0;
+        for (long long r = r0; r < r1; ++r) s += (double)x[r * cols + c];
+        part[(size_t)blockIdx.x * cols + c] = (float)s;
     }
 }

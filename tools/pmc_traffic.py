@@ -9,13 +9,13 @@ CLASSES = [("edge_fused_kernel", "false", "edge_x2h"), ("edge_fused_kernel", "tr
            ("node_linear16_kernel", "", "node_pre"), ("node_linear6_kernel", "", "node_pre"), ("node_linear_kernel", "", "node_pre"),
            ("node_prologue16_kernel", "", "node_prologue"), ("node_prologue6_kernel", "", "node_prologue"), ("vn_stats_kernel", "", "vn_stats"),
            ("vn_apply_kernel", "", "vn_apply"), ("knn_kernel", "", "knn"), ("edge_weight_kernel", "", "edge_weight"),
-           ("ddpm_step", "", "ddpm")]
+           ("graph_kernel", "", "graph"), ("combine32_kernel", "", "edge_combine"), ("ddpm_step", "", "ddpm")]
 
 
 def classify(name):
     if "x2h_chain16_kernel" in name:
         return "edge_x2h_chain"
-    m = re.search(r"edge(?:_fused|16|16x2)_kernel<\d+, \d+, (false|true)", name)      # third template argument: H2X
+    m = re.search(r"edge(?:_fused|16|16_loop)_kernel<\d+, \d+, (false|true)", name)      # third template argument: H2X
     if m:
         return "edge_h2x" if m.group(1) == "true" else "edge_x2h"
     for key, flag, cls in CLASSES:

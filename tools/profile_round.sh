@@ -39,10 +39,11 @@ for SET in "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_
 done
 echo "sq done" >&2
 
-cp "$OUT"/pmc_traffic*.json profiles/r02_final/      # bench.py reads its `traffic` field from the committed summaries
+mkdir -p profiles/r03 && cp "$OUT"/pmc_traffic*.json profiles/r03/      # bench.py reads its `traffic` field from the committed summaries
 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_line_20steps.json" 2> "$OUT/bench_line_20steps.err"
 python3 bench.py --batch 1024 --steps 100 --cpu-steps 0 > "$OUT/bench_line_b1024.json" 2> "$OUT/bench_line_b1024.err"
+python3 bench.py --batch 512 --atoms 40,80 --knn 32 --steps 60 --cpu-steps 0 --concurrent 0 > "$OUT/bench_line_k32_b512.json" 2> "$OUT/bench_line_k32_b512.err"
 # keep only the summaries (the raw traces are large)
 rm -rf "$OUT"/trace* "$OUT"/pmc_FETCH* "$OUT"/pmc_WRITE* "$OUT"/sq[0-9]
 ls -la "$OUT" >&2
