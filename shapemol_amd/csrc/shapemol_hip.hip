@@ -483,7 +483,6 @@ struct shapemol_ctx {
     int x2h_chain = 1;          // 1: x2h attention and the node stage of a layer in one launch (x2h_chain16_kernel) when every wave has one job
                                 // launch (measured: 28.5 us against 15.3 + 11.1 us, eight dependent weight blocks per wave)
     int node_f16 = 1;           // node kernels on two-piece f16 operands (sm_node16.h) instead of exactly split bf16 (sm_node.h)
-    int wt_stores = 0;          // 1: write-through (sc1) stores of the per-node products (node_linear16_kernel)
     int edge_tiles = -1;        // f16 edge kernels when the waves have several jobs: 0 = sliced launches of the one-job kernel,
                                 // 1 = one looping launch (eight waves per workgroup, next job's rows prefetched), -1 = automatic (= 1) [default]
     float hid_max = 0.f;        // bound of the edge MLPs' hidden activations (LayerNorm outputs): must fit fp16 for edge_bf16 = 3
@@ -800,7 +799,7 @@ int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float 
     const int tpg = std::max(1, (n_ct + want_groups - 1) / want_groups);
     const int agroups = (n_ct + tpg - 1) / tpg;
     const bool f16 = c->lin_bf16 && c->node_f16;
-    NodeLinArgs a{in, f16 ? wimg16 : (c->lin_bf16 ? wimg6 : wimg), add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps, nwave, c->wt_stores};
+    NodeLinArgs a{in, f16 ? wimg16 : (c->lin_bf16 ? wimg6 : wimg), add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps, nwave};
     if (f16) {
         const size_t shm = (size_t)std::min(tpg, kLin16Chunk) * 2 * H * 32;
         LAUNCH(name, SMK(node_linear16_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a, c->status + ST_RANGE));
@@ -1307,7 +1306,6 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     }
     else if (k == "edge_tiles") { if (value < -1 || value > 1) return fail("edge_tiles must be -1 (automatic), 0 (sliced one-job launches) or 1 (looping launch)"); c->edge_tiles = (int)value; }
     else if (k == "node_f16") c->node_f16 = value != 0;
-    else if (k == "wt_stores") c->wt_stores = value != 0;
     else if (k == "lin_fuse") c->lin_fuse = value != 0;
     else if (k == "x2h_chain") c->x2h_chain = value != 0;
     else if (k == "graph_fuse") c->graph_fuse = value != 0;

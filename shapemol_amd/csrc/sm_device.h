@@ -51,13 +51,6 @@ SM_DEV f32x4 mfma16(float a, float b, f32x4 c) {
 
 SM_DEV float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 SM_DEV void stg4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
-// 16-byte write-through store (sc1): the line leaves the XCD's L2 while the kernel runs instead of staying dirty until the
-// end-of-kernel write-back (a dependent kernel boundary costs + dirty bytes / ~6 TB/s: 22.7 MB of per-node products = 3.8 us),
-// and it is not kept in this XCD's L2, whose other seven eighths of the readers could not use it anyway.
-SM_DEV void stg4_wt(float *p, float4 v) {
-    const f32x4 d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
-}
 
 // Cooperative global -> LDS copy of `n4` float4 by all `nthr` threads of the workgroup, eight
 // independent 16-byte loads in flight per thread (a plain copy loop is serialised on the L2 latency).

@@ -39,7 +39,6 @@ struct NodeLinArgs {
     int ld_add, ld_out;           // row strides of add_mol and out (floats)
     unsigned long long *stamps;   // diagnostic build only
     int nwave;                    // waves per workgroup (node_linear16_kernel reads it here instead of blockDim)
-    int wt;                       // node_linear16_kernel: write-through (sc1) stores of the output rows (option wt_stores)
 };
 
 constexpr int kLinChunk = 8;      // column tiles staged in LDS at a time (shared by the workgroup's waves)

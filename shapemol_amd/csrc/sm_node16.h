@@ -87,13 +87,8 @@ node_linear16_kernel(NodeLinArgs a, int *range_flag) {
                 acc0 = mfma_f16(w[0][b], l0, acc0); acc1 = mfma_f16(w[0][b], l1, acc1);
                 acc0 = mfma_f16(w[0][b], h0, acc0); acc1 = mfma_f16(w[0][b], h1, acc1);
             }
-            if (a.wt) {
-                if (ot_ok && atom0 < a.n_atoms) stg4_wt(a.out + (size_t)atom0 * a.ld_out + 16 * ot + 4 * g, float4{acc0[0], acc0[1], acc0[2], acc0[3]});
-                if (ot_ok && two && atom1 < a.n_atoms) stg4_wt(a.out + (size_t)atom1 * a.ld_out + 16 * ot + 4 * g, float4{acc1[0], acc1[1], acc1[2], acc1[3]});
-            } else {
-                if (ot_ok && atom0 < a.n_atoms) stg4(a.out + (size_t)atom0 * a.ld_out + 16 * ot + 4 * g, float4{acc0[0], acc0[1], acc0[2], acc0[3]});
-                if (ot_ok && two && atom1 < a.n_atoms) stg4(a.out + (size_t)atom1 * a.ld_out + 16 * ot + 4 * g, float4{acc1[0], acc1[1], acc1[2], acc1[3]});
-            }
+            if (ot_ok && atom0 < a.n_atoms) stg4(a.out + (size_t)atom0 * a.ld_out + 16 * ot + 4 * g, float4{acc0[0], acc0[1], acc0[2], acc0[3]});
+            if (ot_ok && two && atom1 < a.n_atoms) stg4(a.out + (size_t)atom1 * a.ld_out + 16 * ot + 4 * g, float4{acc1[0], acc1[1], acc1[2], acc1[3]});
         }
         SM_TICK(a.stamps, 3);
     }
