@@ -311,7 +311,7 @@ def main():
             log(f"concurrent chains: {out['concurrent_chains']}")
             del runners
         # ---- the same chain with exactly split operands (fp32-exact products), driver-timed like `value` ----
-        if world == 1 and args.exact_steps > 0 and use_graph and not args.opt:
+        if world == 1 and args.exact_steps > 0 and use_graph and not args.opt and cfg["knn"] <= 16:       # (k > 16 has no bf16 path)
             es = min(args.exact_steps, runner.max_steps)
             model.set_option("edge_bf16", 1)
             model.set_option("node_f16", 0)

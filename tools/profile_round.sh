@@ -7,13 +7,13 @@ set -eo pipefail
 OUT=${1:-gpurun_out/prof_round}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-SHORT="--steps 20 --warmup 5 --cpu-steps 0 --profile-steps 2 --eager --concurrent 0"
+SHORT="--steps 20 --warmup 5 --cpu-steps 0 --profile-steps 2 --eager --concurrent 0 --exact-steps 0"
 find_csv() { find "$1" -name "*$2" | head -1; }
 
 for B in 256 1024; do
   tag=$([ $B = 256 ] && echo "" || echo "_b$B")
   steps=$([ $B = 256 ] && echo 300 || echo 100)
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace$tag" -- python3 bench.py --batch $B --steps $steps --warmup 20 --cpu-steps 0 --concurrent 0 \
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace$tag" -- python3 bench.py --batch $B --steps $steps --warmup 20 --cpu-steps 0 --concurrent 0 --exact-steps 0 \
       > "$OUT/bench_line${tag}_profiled.json" 2> "$OUT/trace$tag.err"
   cp "$(find_csv "$OUT/trace$tag" _kernel_stats.csv)" "$OUT/kernel_stats$tag.csv"
   [ $B = 256 ] && python3 tools/trace_gaps.py "$(find_csv "$OUT/trace$tag" _kernel_trace.csv)" > "$OUT/per_step_breakdown.txt"
