@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the HIP path against the CPU oracle (GPU box): forwards and short chains over random batch
 sizes, molecule sizes, neighbour counts k and time steps, every kernel family the launch logic can pick (one-job and
-sliced f16 edge kernels, the two-tile kernel for k > 16, folded and separate coordinate updates).
-    python tools/fuzz_parity.py [--cases 40] [--seed 1] > profiles/r02_final/fuzz_parity.txt"""
+sliced f16 edge kernels, half-atom tiles + merge for k > 16, looping launches, folded and separate coordinate updates).
+    python tools/fuzz_parity.py [--cases 40] [--seed 1] > profiles/r03/fuzz_parity.txt"""
 import argparse
 import os
 import sys
