@@ -330,6 +330,24 @@ def main():
             finally:
                 model.set_option("edge_bf16", 3)
                 model.set_option("node_f16", 1)
+        # ---- reduced precision: "f16 features" (BASELINE configs[2] names a reduced-precision feature mode; NOT a parity mode) ----
+        if world == 1 and args.exact_steps > 0 and use_graph and not args.opt:
+            es = min(args.exact_steps, runner.max_steps)
+            model.set_option("feat_f16", 1)
+            try:
+                runner.run(max(1, min(warm, es)), seed=41, use_graph=True)
+                runner.synchronize()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                runner.run(es, seed=42, use_graph=True)
+                runner.synchronize()
+                dtf = (time.perf_counter() - t1) / es
+                out["f16_features_mode"] = {"value": round(args.batch / (CHAIN_STEPS * dtf), 3), "unit": "molecules/s", "ms_per_step": round(dtf * 1e3, 4),
+                                            "steps": es, "dtype": "f16 matrix operands (11 bits, one product per term), fp32 accumulate / LayerNorm / softmax / coordinates",
+                                            "options": ["feat_f16=1"], "note": "reduced precision, outside the parity gates (forward error ~1e-3)"}
+                log(f"f16 features mode: {out['f16_features_mode']}")
+            finally:
+                model.set_option("feat_f16", 0)
         # trajectory D2H cost (reported, never part of value)
         if not args.no_traj:
             torch.cuda.synchronize()

@@ -199,6 +199,10 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
  *          "node_f16"   (1 = node kernels (prologue, chain, per-node products) on two-piece f16 operands [default]: the
  *                        residual stream then passes through fp16 pieces, |x| >= 6e4 raises a status flag;
  *                        0 = the same kernels on exactly split bf16 operands, six products per term),
+ *          "feat_f16"   (1 = "f16 features": every matrix product of the f16 kernels on the leading f16 piece of both operands
+ *                        only -- one product per term instead of three, 11 significand bits in the operands; accumulation,
+ *                        LayerNorm, softmax, coordinates, batch statistics stay fp32.  A reduced-precision throughput mode
+ *                        (forward error ~1e-3), outside the parity gates; 0 = two-piece operands [default]),
  *          "lin_bf16", "chain_bf16" (1 = node kernels on the matrix cores with split operands [default],
  *                        0 = fp32-MFMA node kernels),
  *          "edge_tiles" (f16 edge kernels when the waves have several jobs (batches beyond ~6k atoms, k > 16): 1 = one looping

@@ -483,6 +483,8 @@ struct shapemol_ctx {
     int x2h_chain = 1;          // 1: x2h attention and the node stage of a layer in one launch (x2h_chain16_kernel) when every wave has one job
                                 // launch (measured: 28.5 us against 15.3 + 11.1 us, eight dependent weight blocks per wave)
     int node_f16 = 1;           // node kernels on two-piece f16 operands (sm_node16.h) instead of exactly split bf16 (sm_node.h)
+    int feat_f16 = 0;           // 1: "f16 features" -- matrix products on the leading f16 piece only (one product per term instead of
+                                // three; accumulation, LayerNorm, softmax, coordinates fp32).  Reduced precision, NOT a parity mode
     int edge_tiles = -1;        // f16 edge kernels when the waves have several jobs: 0 = sliced launches of the one-job kernel,
                                 // 1 = one looping launch (eight waves per workgroup, next job's rows prefetched), -1 = automatic (= 1) [default]
     float hid_max = 0.f;        // bound of the edge MLPs' hidden activations (LayerNorm outputs): must fit fp16 for edge_bf16 = 3
@@ -629,17 +631,29 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)node_prologue16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * Chain16Lds<H>::FRAG * 16 + Chain16Lds<H>::PRE * 4)));
     HIPCHK(hipFuncSetAttribute((const void *)node_chain16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain16Lds<H>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)node_linear16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin16Chunk * 2 * H * 32));
+    HIPCHK(hipFuncSetAttribute((const void *)node_prologue16_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * Chain16Lds<H>::FRAG * 16 + Chain16Lds<H>::PRE * 4)));
+    HIPCHK(hipFuncSetAttribute((const void *)node_chain16_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Chain16Lds<H>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)node_linear16_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLin16Chunk * 2 * H * 32));
 #define SETATTR4(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)x2h_chain16_kernel<H, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes));
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)x2h_chain16_kernel<H, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes)); \
+    HIPCHK(hipFuncSetAttribute((const void *)x2h_chain16_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4 + kVnFoldBytes));
 #define SETATTR6(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EdgeImage16<H, H / 16>::TOTAL * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
-    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
     if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) } else { SETATTR6(32) }
 #undef SETATTR6
 #undef SETATTR4
@@ -696,7 +710,11 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
     const int tiles_mode = c->edge_tiles >= 0 ? c->edge_tiles : 1;      // -1 = automatic: looping launches
 #define EDGE_DISPATCH(KERNEL, ...)                                                                  \
     do {                                                                                            \
-        if (KP == 8) LAUNCH(nm, SMK((KERNEL<H, 8, H2X>), __VA_ARGS__));                             \
+        if (c->feat_f16) {                                                                          \
+            if (KP == 8) LAUNCH(nm, SMK((KERNEL<H, 8, H2X, true>), __VA_ARGS__));                   \
+            else if (KP == 16) LAUNCH(nm, SMK((KERNEL<H, 16, H2X, true>), __VA_ARGS__));            \
+            else LAUNCH(nm, SMK((KERNEL<H, 32, H2X, true>), __VA_ARGS__));                          \
+        } else if (KP == 8) LAUNCH(nm, SMK((KERNEL<H, 8, H2X>), __VA_ARGS__));                      \
         else if (KP == 16) LAUNCH(nm, SMK((KERNEL<H, 16, H2X>), __VA_ARGS__));                      \
         else LAUNCH(nm, SMK((KERNEL<H, 32, H2X>), __VA_ARGS__));                                    \
     } while (0)
@@ -773,7 +791,10 @@ int launch_x2h_chain(shapemol_ctx *c, hipStream_t s, const Edge16Args &a, const 
     const size_t shm = 2 * EdgeImage16<H, H / 16>::TOTAL * sizeof(float) + (a.vf.enable ? kVnFoldBytes : 0);
     Edge16Args b = a;
     b.job_base = 0; b.job_end = njobs; b.nwave = waves;
-    if (KP == 8) LAUNCH("edge_x2h_chain", SMK((x2h_chain16_kernel<H, 8>), dim3(grid), dim3(waves * 64), shm, s, b, na, c->status + ST_RANGE));
+    if (c->feat_f16) {
+        if (KP == 8) LAUNCH("edge_x2h_chain", SMK((x2h_chain16_kernel<H, 8, true>), dim3(grid), dim3(waves * 64), shm, s, b, na, c->status + ST_RANGE));
+        else LAUNCH("edge_x2h_chain", SMK((x2h_chain16_kernel<H, 16, true>), dim3(grid), dim3(waves * 64), shm, s, b, na, c->status + ST_RANGE));
+    } else if (KP == 8) LAUNCH("edge_x2h_chain", SMK((x2h_chain16_kernel<H, 8>), dim3(grid), dim3(waves * 64), shm, s, b, na, c->status + ST_RANGE));
     else LAUNCH("edge_x2h_chain", SMK((x2h_chain16_kernel<H, 16>), dim3(grid), dim3(waves * 64), shm, s, b, na, c->status + ST_RANGE));
     return 0;
 }
@@ -802,7 +823,8 @@ int launch_linear(shapemol_ctx *c, hipStream_t s, const char *name, const float 
     NodeLinArgs a{in, f16 ? wimg16 : (c->lin_bf16 ? wimg6 : wimg), add_mol, c->mol_of, out, n_atoms, n_out_tiles, tpg, ld_add, ld_out, stamps, nwave};
     if (f16) {
         const size_t shm = (size_t)std::min(tpg, kLin16Chunk) * 2 * H * 32;
-        LAUNCH(name, SMK(node_linear16_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a, c->status + ST_RANGE));
+        if (c->feat_f16) LAUNCH(name, SMK((node_linear16_kernel<H, true>), dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a, c->status + ST_RANGE));
+        else LAUNCH(name, SMK(node_linear16_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a, c->status + ST_RANGE));
     } else if (c->lin_bf16) {
         const size_t shm = (size_t)std::min(tpg, kLin6Chunk) * 3 * H * 32;
         LAUNCH(name, SMK(node_linear6_kernel<H>, dim3(ogroups * agroups), dim3(nwave * 64), shm, s, a));
@@ -860,7 +882,9 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         pa.n_atoms = n; pa.C = C; pa.D = D; pa.t_first = t_first; pa.bn_acc_len = ae.bn_acc_len;
         pa.stamps = c->kstamp_sel == 5 ? c->kstamps : nullptr;
         const int n_ct = (n + 15) / 16;
-        if (c->node_f16) LAUNCH("node_prologue", SMK(node_prologue16_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
+        if (c->node_f16 && c->feat_f16) LAUNCH("node_prologue", SMK((node_prologue16_kernel<H, true>), dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
+                                                   2 * Chain16Lds<H>::FRAG * 16 + Chain16Lds<H>::PRE * 4, s, pa, c->status + ST_RANGE));
+        else if (c->node_f16) LAUNCH("node_prologue", SMK(node_prologue16_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
                                                    2 * Chain16Lds<H>::FRAG * 16 + Chain16Lds<H>::PRE * 4, s, pa, c->status + ST_RANGE));
         else LAUNCH("node_prologue", SMK(node_prologue6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4),
                                                    2 * Chain6Lds<H>::FRAG * 16 + Chain6Lds<H>::PRE * 4, s, pa));
@@ -950,6 +974,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                 na.pre_out = c->preAB; na.n_lin_tiles = lin_tiles; na.ld_add = 8 * H; na.ld_out = 8 * H;
             }
             if (xc_fused) { if (launch_x2h_chain<H>(c, s, xea, na)) return 1; }
+            else if (c->chain_bf16 && c->node_f16 && c->feat_f16) LAUNCH("node_chain", SMK((node_chain16_kernel<H, true>), dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain16Lds<H>::BYTES, s, na, c->status + ST_RANGE));
             else if (c->chain_bf16 && c->node_f16) LAUNCH("node_chain", SMK(node_chain16_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain16Lds<H>::BYTES, s, na, c->status + ST_RANGE));
             else if (c->chain_bf16) LAUNCH("node_chain", SMK(node_chain6_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain6Lds<H>::BYTES, s, na));
             else LAUNCH("node_chain", SMK(node_chain_kernel<H>, dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), 0, s, na));
@@ -1306,6 +1331,10 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     }
     else if (k == "edge_tiles") { if (value < -1 || value > 1) return fail("edge_tiles must be -1 (automatic), 0 (sliced one-job launches) or 1 (looping launch)"); c->edge_tiles = (int)value; }
     else if (k == "node_f16") c->node_f16 = value != 0;
+    else if (k == "feat_f16") {
+        if (value && (c->edge_bf16 != 3 || !c->node_f16)) return fail("feat_f16 = 1 needs the f16 kernels (edge_bf16 = 3, node_f16 = 1)");
+        c->feat_f16 = value != 0;
+    }
     else if (k == "lin_fuse") c->lin_fuse = value != 0;
     else if (k == "x2h_chain") c->x2h_chain = value != 0;
     else if (k == "graph_fuse") c->graph_fuse = value != 0;

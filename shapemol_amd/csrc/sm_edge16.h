@@ -76,31 +76,37 @@ struct EdgeImage16 {
 };
 
 // acc[t] += W1[:, 0:20] rbf for all NT tiles: one K = 32 step, three products per tile
-template <int NT>
+// P1 (option feat_f16, "f16 features"): only the leading f16 piece of both operands -- one product per term instead of three,
+// 11 significand bits in the matrix operands (accumulation, LayerNorm, softmax, coordinates stay fp32).  Not a parity mode.
+template <int NT, bool P1 = false>
 SM_DEV void first_linear16(const unsigned *w1, u32x4 rh, u32x4 rl, f32x4 (&acc)[NT], int lane) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const unsigned *ph = w1 + (0 * NT + t) * 192 + lane, *pl = w1 + (1 * NT + t) * 192 + lane;
         const u32x4 ah = {ph[0], ph[64], ph[128], 0u};
-        const u32x4 al = {pl[0], pl[64], pl[128], 0u};
         f32x4 c = acc[t];
-        c = mfma_f16(al, rh, c);      // smallest terms first
-        c = mfma_f16(ah, rl, c);
+        if constexpr (!P1) {
+            const u32x4 al = {pl[0], pl[64], pl[128], 0u};
+            c = mfma_f16(al, rh, c);      // smallest terms first
+            c = mfma_f16(ah, rl, c);
+        }
         c = mfma_f16(ah, rh, c);
         acc[t] = c;
     }
 }
 
 // one output tile of the second Linear
-template <int NT, int NT2>
+template <int NT, int NT2, bool P1 = false>
 SM_DEV f32x4 tile_f16x3(const unsigned *w2, int t2, const u32x4 (&bh)[NT / 2], const u32x4 (&bl)[NT / 2], f32x4 c, int lane) {
     constexpr int NB = NT / 2;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const u32x4 ah = *reinterpret_cast<const u32x4 *>(w2 + (((0 * NT2 + t2) * NB + b) * 64 + lane) * 4);
-        const u32x4 al = *reinterpret_cast<const u32x4 *>(w2 + (((1 * NT2 + t2) * NB + b) * 64 + lane) * 4);
-        c = mfma_f16(al, bh[b], c);
-        c = mfma_f16(ah, bl[b], c);
+        if constexpr (!P1) {
+            const u32x4 al = *reinterpret_cast<const u32x4 *>(w2 + (((1 * NT2 + t2) * NB + b) * 64 + lane) * 4);
+            c = mfma_f16(al, bh[b], c);
+            c = mfma_f16(ah, bl[b], c);
+        }
         c = mfma_f16(ah, bh[b], c);
     }
     return c;
@@ -160,7 +166,7 @@ struct Edge16Args {
 // two tiles of an atom with the weights s_t exp(m_t - M) / sum_t s_t exp(m_t - M) (the "online softmax" identity).  No wave
 // ever holds two tiles, so k = 32 runs in the same registers as k = 8 (the two-tile kernel of round 2 needed 256 VGPRs and
 // spilled 40-75); the VN-linear epilogue is not fused for k > 16 (vn_stats_kernel / vn_apply_kernel follow the combine).
-template <int H, int KP, bool H2X, bool ONE, bool KEEP>
+template <int H, int KP, bool H2X, bool ONE, bool KEEP, bool P1 = false>
 SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
     static_assert(KP == 8 || KP == 16 || KP == 32, "16-slot tiles");
     static_assert(!KEEP || (ONE && !H2X && KP <= 16), "KEEP: one-job x2h only");
@@ -258,7 +264,7 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
             for (int t = 0; t < NT; ++t)
                 acc[t] = f32x4{ra[t].x + rbw[t].x, ra[t].y + rbw[t].y, ra[t].z + rbw[t].z, ra[t].w + rbw[t].w};
             after_rows();
-            first_linear16<NT>(reinterpret_cast<const unsigned *>(img) + IM::O_W1, rh, rl, acc, lane);
+            first_linear16<NT, P1>(reinterpret_cast<const unsigned *>(img) + IM::O_W1, rh, rl, acc, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1];
@@ -416,14 +422,14 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
 #pragma unroll
             for (int t = 0; t < NT / 2; ++t) alpha[t] = qv[t].x * __builtin_bit_cast(float, kh[t][0] & 0x3fffffffu);
         } else {
-            f32x4 ka = tile_f16x3<NT, NT>(w2k, 0, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
-            f32x4 kb = tile_f16x3<NT, NT>(w2k, NT / 2, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+            f32x4 ka = tile_f16x3<NT, NT, P1>(w2k, 0, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+            f32x4 kb = tile_f16x3<NT, NT, P1>(w2k, NT / 2, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
 #pragma unroll
             for (int t = 0; t < NT / 2; ++t) {
                 f32x4 na = ka, nb = kb;
                 if (t + 1 < NT / 2) {
-                    na = tile_f16x3<NT, NT>(w2k, t + 1, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
-                    nb = tile_f16x3<NT, NT>(w2k, t + 1 + NT / 2, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+                    na = tile_f16x3<NT, NT, P1>(w2k, t + 1, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+                    nb = tile_f16x3<NT, NT, P1>(w2k, t + 1 + NT / 2, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
                 }
                 if constexpr (HALF) {        // this tile's softmax state of head 2 (t + (NT/2)(g & 1)) + (g >> 1), for the combine
                     float mx, ssum;
@@ -461,7 +467,7 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const f32x4 v = SM_ABL(20) ? f32x4{__builtin_bit_cast(float, vh[t % (NT / 2)][0] & 0x3fffffffu), 1.f, 2.f, 3.f}
-                                               : tile_f16x3<NT, NT>(w2v, t, vh, vl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+                                               : tile_f16x3<NT, NT, P1>(w2v, t, vh, vl, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
                     const float4 bb = ldg4(b2 + 16 * t + 4 * g);
                     const float aw = al[t];
                     const float sw = seg_sum<SEGW>(aw);
@@ -474,7 +480,7 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
                 }
             } else {
                 const float4 bb = ldg4(b2 + 4 * g);
-                const f32x4 vacc = tile_f16x3<NT, 1>(w2v, 0, vh, vl, f32x4{bb.x, bb.y, bb.z, bb.w}, lane);
+                const f32x4 vacc = tile_f16x3<NT, 1, P1>(w2v, 0, vh, vl, f32x4{bb.x, bb.y, bb.z, bb.w}, lane);
                 // value row 4g + r belongs to head 2*((NT/2)*(g&1) + r) + (g>>1) = the head of the lane's own alpha[r]
                 float o[12];
 #pragma unroll
@@ -573,18 +579,18 @@ SM_DEV void edge16_body(const Edge16Args &a, float4 (&keep)[H / 16]) {
     }
 }
 
-template <int H, int KP, bool H2X>
+template <int H, int KP, bool H2X, bool P1 = false>
 __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
 edge16_kernel(Edge16Args a) {          // one job per wave, up to twelve waves per workgroup
     float4 keep[H / 16];
-    edge16_body<H, KP, H2X, true, false>(a, keep);
+    edge16_body<H, KP, H2X, true, false, P1>(a, keep);
 }
 
-template <int H, int KP, bool H2X>
+template <int H, int KP, bool H2X, bool P1 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 edge16_loop_kernel(Edge16Args a) {     // eight waves per workgroup looping over a.chunk consecutive jobs
     float4 keep[H / 16];
-    edge16_body<H, KP, H2X, false, false>(a, keep);
+    edge16_body<H, KP, H2X, false, false, P1>(a, keep);
 }
 
 // k > 16: merge the two half-atom tiles of every atom.  part [2 N][W] rows (W = H for x2h, 48 for h2x: [16 rows][3] with row

@@ -25,7 +25,7 @@ SM_DEV void split2_8(const float (&v)[8], u32x4 &hi, u32x4 &lo, int *range_flag)
 // split f16 image of a Linear: wimg[(((ot * 2 + piece) * NB + b) * 64 + lane) * 4 + q] u32, element order of gemm_bf16x6
 constexpr int kLin16Chunk = 12;   // column tiles staged at a time: 2 * H * 32 bytes each (8 KB at H = 128)
 
-template <int H>
+template <int H, bool P1 = false>
 __global__ void __launch_bounds__(kNodeThreads)
 node_linear16_kernel(NodeLinArgs a, int *range_flag) {
     constexpr int NB = H / 32;
@@ -83,8 +83,10 @@ node_linear16_kernel(NodeLinArgs a, int *range_flag) {
             for (int b = 0; b < NB; ++b) {
                 const u32x4 h0 = f0[b * 64], l0 = f0[(NB + b) * 64];
                 const u32x4 h1 = f1[b * 64], l1 = f1[(NB + b) * 64];
-                acc0 = mfma_f16(w[1][b], h0, acc0); acc1 = mfma_f16(w[1][b], h1, acc1);      // smallest terms first
-                acc0 = mfma_f16(w[0][b], l0, acc0); acc1 = mfma_f16(w[0][b], l1, acc1);
+                if constexpr (!P1) {
+                    acc0 = mfma_f16(w[1][b], h0, acc0); acc1 = mfma_f16(w[1][b], h1, acc1);      // smallest terms first
+                    acc0 = mfma_f16(w[0][b], l0, acc0); acc1 = mfma_f16(w[0][b], l1, acc1);
+                }
                 acc0 = mfma_f16(w[0][b], h0, acc0); acc1 = mfma_f16(w[0][b], h1, acc1);
             }
             if (ot_ok && atom0 < a.n_atoms) stg4(a.out + (size_t)atom0 * a.ld_out + 16 * ot + 4 * g, float4{acc0[0], acc0[1], acc0[2], acc0[3]});
@@ -105,7 +107,7 @@ struct Chain16Lds {
 };
 
 // shared device pieces of the chain / prologue kernels
-template <int H>
+template <int H, bool P1 = false>
 struct Node16 {
     static constexpr int NB = H / 32, CC = CHAIN_COLS, XS = Chain16Lds<H>::XS, LPC = NB * 4;
     // w[2][KB]: this wave's block of a split image
@@ -128,10 +130,12 @@ struct Node16 {
                 xh[c] = f[((0 * KB + b) * CC + c) * 64 + frag_slot(b, lane)];
                 xl[c] = f[((1 * KB + b) * CC + c) * 64 + frag_slot(b, lane)];
             }
+            if constexpr (!P1) {
 #pragma unroll
-            for (int c = 0; c < CC; ++c) acc[c] = mfma_f16(w[1][b], xh[c], acc[c]);      // smallest terms first
+                for (int c = 0; c < CC; ++c) acc[c] = mfma_f16(w[1][b], xh[c], acc[c]);      // smallest terms first
 #pragma unroll
-            for (int c = 0; c < CC; ++c) acc[c] = mfma_f16(w[0][b], xl[c], acc[c]);
+                for (int c = 0; c < CC; ++c) acc[c] = mfma_f16(w[0][b], xl[c], acc[c]);
+            }
 #pragma unroll
             for (int c = 0; c < CC; ++c) acc[c] = mfma_f16(w[0][b], xh[c], acc[c]);
         }
@@ -181,10 +185,10 @@ struct Node16 {
 //                  becomes the fragment buffers, so a barrier separates the two uses.  Weights and h rows are requested
 //                  BEFORE that barrier (a wave that has finished its edge job has its registers free while the slower
 //                  waves finish theirs).  Waves >= NT help with the staging and retire.
-template <int H, bool FUSED, int SEGW>
+template <int H, bool FUSED, int SEGW, bool P1 = false>
 SM_DEV void chain16_body(const NodeChainArgs &a, int *range_flag, int first_atom, int ncols, const float4 (&keep)[H / 16], int nthreads) {
     using L = Chain16Lds<H>;
-    using N16 = Node16<H>;
+    using N16 = Node16<H, P1>;
     constexpr int NT = H / 16, NB = H / 32, CC = CHAIN_COLS;
     static_assert(CC == 2, "the normalise pass covers exactly 32 columns");
     extern __shared__ __attribute__((aligned(16))) unsigned char chain16_lds[];
@@ -395,32 +399,32 @@ SM_DEV void chain16_body(const NodeChainArgs &a, int *range_flag, int first_atom
     SM_STAMP(a.stamps, 7);
 }
 
-template <int H>
+template <int H, bool P1 = false>
 __global__ void __launch_bounds__(H * 4)
 node_chain16_kernel(NodeChainArgs a, int *range_flag) {
     float4 keep[H / 16];
-    chain16_body<H, false, 8>(a, range_flag, blockIdx.x * CHAIN_COLS * 16, CHAIN_COLS * 16, keep, H * 4);
+    chain16_body<H, false, 8, P1>(a, range_flag, blockIdx.x * CHAIN_COLS * 16, CHAIN_COLS * 16, keep, H * 4);
 }
 
 // x2h attention and the node stage of the same layer in one launch (one job per wave, >= H / 16 waves per workgroup): the
 // attention rows of a workgroup's atoms never leave the CU, the node stage's first weights are requested while the slower
 // waves still finish their edge jobs, and one launch (with its ramp, drain and cache write-back) per layer disappears.
-template <int H, int KP>
+template <int H, int KP, bool P1 = false>
 __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
 x2h_chain16_kernel(Edge16Args e, NodeChainArgs a, int *range_flag) {
     float4 keep[H / 16];
-    edge16_body<H, KP, false, true, true>(e, keep);
+    edge16_body<H, KP, false, true, true, P1>(e, keep);
     const int nwave = e.nwave, apj = 16 / KP;
     const int first_atom = (e.job_base + blockIdx.x * nwave) * apj;
-    chain16_body<H, true, KP>(a, range_flag, first_atom, nwave * apj, keep, nwave * 64);
+    chain16_body<H, true, KP, P1>(a, range_flag, first_atom, nwave * apj, keep, nwave * 64);
 }
 
-template <int H>
+template <int H, bool P1 = false>
 __global__ void __launch_bounds__(H * 4)
 node_prologue16_kernel(NodePrologueArgs a, int *range_flag) {
     SM_TICK(a.stamps, 0);
     using L = Chain16Lds<H>;
-    using N16 = Node16<H>;
+    using N16 = Node16<H, P1>;
     constexpr int NT = H / 16, NB = H / 32, CC = CHAIN_COLS, XS = L::XS;
     extern __shared__ __attribute__((aligned(16))) unsigned char chain16_lds[];
     u32x4 *fh = reinterpret_cast<u32x4 *>(chain16_lds);      // fragments of h0
