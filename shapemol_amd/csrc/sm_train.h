@@ -84,13 +84,25 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
         }
 }
 
-// out[i] = sum_s part[s * n + i], s ascending (the fixed order that makes the parameter gradients deterministic)
+// out[i] = sum_s part[s * n + i] in a fixed order (which makes the parameter gradients deterministic): a workgroup owns 32
+// outputs, its 8 thread groups add every 8th partial (float64: partials of sums that cancel -- a bias in front of a
+// LayerNorm), the first group adds the 8 group sums.  (One thread per output walking all partials was a chain of up to 256
+// dependent loads: 27 % of a training step.)
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float *part, int n_parts, long long n, float *out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;                 // (partials of sums that cancel -- a bias in front of a LayerNorm -- are added in float64)
-    for (int p = 0; p < n_parts; ++p) s += (double)part[(size_t)p * n + i];
-    out[i] = (float)s;
+    __shared__ double grp[8][32];
+    const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + col;
+    double s = 0.0;
+    if (i < n)
+        for (int p = g; p < n_parts; p += 8) s += (double)part[(size_t)p * n + i];
+    grp[g][col] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += grp[k][col];
+        out[i] = (float)t;
+    }
 }
 
 // LayerNorm + ReLU of the rows of z [rows][H] (in place: z becomes the activation a), keeping xhat and rstd for the backward.

@@ -29,14 +29,13 @@ int gemm(hipStream_t s, const float *A, long long sam, long long sak, const floa
     return 0;
 }
 int reduce_parts(hipStream_t s, const float *part, int n_parts, long long n, float *out) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, n_parts, n, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, n_parts, n, out);
     TRCHK(hipGetLastError());
     return 0;
 }
-// row-reduction splits of the two weight-gradient products: with the 2 x 5 (dW1) / 2 x 2 (dW2) output tiles enough workgroups to
-// fill the chip, at least 256 rows each; more splits only make the partial sums longer (256 splits: the reduce kernel took
-// 27 % of a training step, rocprofv3, profiles/r03/train_kernel_stats_first.csv)
-int row_splits(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(32, rows / 256)); }
+// row-reduction splits of the two weight-gradient products: many short splits (the strided GEMM is latency-bound per workgroup:
+// 32 splits made a training step 10 ms slower than 256), at least 256 rows each
+int row_splits(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, rows / 256)); }
 // the number of splits gemm() will really launch for K = rows
 int real_splits(int64_t rows) {
     const int sp = row_splits(rows);
