@@ -42,19 +42,31 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool a_kfast = a.sak == 1, b_nfast = a.sbn == 1;
-    for (int k0 = k_begin; k0 < k_end; k0 += kGemmKC) {
-        // stage the 64 x 16 tile of A and the 16 x 64 tile of B (zero-padded), consecutive threads along the unit stride
+    // the 64 x 16 tile of A and the 16 x 64 tile of B (zero-padded), consecutive threads along the unit stride; the NEXT chunk's
+    // elements are requested into registers before the current chunk's products (they fly under the MFMAs)
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;
             const int m = a_kfast ? e / kGemmKC : e % 64, k = a_kfast ? e % kGemmKC : e / 64;
             const int gm = m0 + m, gk = k0 + k;
-            As[m][k] = (gm < a.M && gk < k_end) ? a.A[(long long)gm * a.sam + (long long)gk * a.sak] : 0.f;
+            ra[i] = (gm < a.M && gk < k_end) ? a.A[(long long)gm * a.sam + (long long)gk * a.sak] : 0.f;
             const int n = b_nfast ? e % 64 : e / kGemmKC, kb = b_nfast ? e / 64 : e % kGemmKC;
             const int gn = n0 + n, gkb = k0 + kb;
-            Bs[kb][n] = (gn < a.N && gkb < k_end) ? a.B[(long long)gkb * a.sbk + (long long)gn * a.sbn] : 0.f;
+            rb[i] = (gn < a.N && gkb < k_end) ? a.B[(long long)gkb * a.sbk + (long long)gn * a.sbn] : 0.f;
+        }
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += kGemmKC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            As[a_kfast ? e / kGemmKC : e % 64][a_kfast ? e % kGemmKC : e / 64] = ra[i];
+            Bs[b_nfast ? e / 64 : e % kGemmKC][b_nfast ? e % 64 : e / kGemmKC] = rb[i];
         }
         __syncthreads();
+        if (k0 + kGemmKC < k_end) fetch(k0 + kGemmKC);
 #pragma unroll
         for (int kk = 0; kk < kGemmKC / 4; ++kk) {
             float af[2], bf[2];
