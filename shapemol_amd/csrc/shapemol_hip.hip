@@ -473,8 +473,6 @@ struct shapemol_ctx {
     int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 3, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
     int vn_fold = 1;            // coordinate update of layer l in the prologue of the x2h kernel of layer l + 1 (needs max_mol_atoms)
     int max_mol_atoms = 0;      // largest molecule of the batches to come (option; 0 = unknown: no fold)
-    int min_mol_atoms = 0;      // smallest molecule of the batches to come (option; 0 = unknown: no helper-wave products)
-    int lin_helpers = 1;        // 1: per-node products by the helper waves of the fused x2h + node-stage launch when it has >= 3 of them
     int lin_fuse = 0;           // 1: per-node products of the next attentions inside node_chain16_kernel instead of a node_linear
     int bn_eval = 0;            // 1: evaluation-mode batch-norm (running statistics, shapemol_set_bn_running) instead of the batch's
     float *bn_run = nullptr;    // [2][L][heads] running mean | running variance (device)
@@ -504,8 +502,8 @@ struct shapemol_ctx {
     // the captured step depends on the batch geometry only: seed, noise and trajectory pointers live in chain_params
     // what a captured step depends on besides the options (which drop the graphs when set): sizes, guidance, and the two
     // launch decisions taken from the max_mol_atoms hint (folded coordinate update, fused graph kernel)
-    struct GraphKey { int64_t N = 0, B = 0; int guided = 0, fold = 0, gfuse = 0, helpers = 0;
-                      bool operator==(const GraphKey &o) const { return N == o.N && B == o.B && guided == o.guided && fold == o.fold && gfuse == o.gfuse && helpers == o.helpers; } } gkey{};
+    struct GraphKey { int64_t N = 0, B = 0; int guided = 0, fold = 0, gfuse = 0;
+                      bool operator==(const GraphKey &o) const { return N == o.N && B == o.B && guided == o.guided && fold == o.fold && gfuse == o.gfuse; } } gkey{};
     hipStream_t gstream = nullptr; bool gstream_set = false;     // the stream the executables were last launched on
     void drop_graphs() {      // a replay may still be in flight: drain it before destroying the executables (only the stream the
         if (!gexec && !gexec_u) return;       // graphs ran on: another context's chain may be running beside, and must not be waited for)
@@ -785,21 +783,6 @@ bool x2h_chain_ok(const shapemol_ctx *c, int n_atoms) {
     return waves <= 12 && waves * apj <= CHAIN_COLS * 16 && njobs <= grid * waves && Chain16Lds<H>::BYTES <= 2 * EdgeImage16<H, H / 16>::TOTAL * 4;
 }
 
-// helper waves of the fused launch that compute the per-node products beside the node stage (lin_helper, sm_node16.h): at least
-// three waves beyond the H / 16 workers, the rings and the term table behind the node stage's LDS, and at most
-// kLinHelperMols molecules under a workgroup's columns (from the min_mol_atoms hint: first and last molecule may contribute one
-// atom each, the ones between at least min_mol_atoms)
-template <int H>
-int lin_helper_waves(const shapemol_ctx *c, int n_atoms, bool sampling) {
-    if (!c->lin_helpers || !sampling || H != 128 || c->min_mol_atoms <= 0 || !x2h_chain_ok<H>(c, n_atoms)) return 0;
-    const int apj = 16 / c->KP, njobs = (n_atoms + apj - 1) / apj;
-    const int waves = std::max(H / 16, edge_waves_for(c, njobs)), ncols = waves * apj;
-    if (waves - H / 16 < 3) return 0;
-    if ((ncols - 2) / c->min_mol_atoms + 2 > kLinHelperMols) return 0;
-    if (Chain16Lds<H>::BYTES + (size_t)kLinRingSlots * kLinSlotBytes + (size_t)kLinHelperMols * 4 * H * 4 > (size_t)2 * EdgeImage16<H, H / 16>::TOTAL * 4) return 0;
-    return 3;
-}
-
 template <int H>
 int launch_x2h_chain(shapemol_ctx *c, hipStream_t s, const Edge16Args &a, const NodeChainArgs &na) {
     const int KP = c->KP, apj = 16 / KP;
@@ -985,16 +968,10 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             else if (out_v) { na.f[1] = follow_of(c, c->dm.vhead, NODE_SSP, out_v, C, C); na.n_follow = 2; v_done = true; }
             const int n_ct = (n + 15) / 16;
             const int lin_tiles = (has_next && l + 1 < L ? 8 : 4) * NT;
-            const int helpers = xc_fused ? lin_helper_waves<H>(c, n, sampling) : 0;
-            const bool lin_fused = (c->chain_bf16 && c->lin_bf16 && c->node_f16 && c->lin_fuse) || helpers > 0;
-            na.lin_helpers = helpers; na.span_flag = c->status + ST_SPAN;
+            const bool lin_fused = c->chain_bf16 && c->lin_bf16 && c->node_f16 && c->lin_fuse;
             if (lin_fused) {
                 na.lin_img16 = c->P(Dl.lin16_img); na.add_mol = c->addp + (size_t)l * c->capB * 8 * H; na.mol_of = c->mol_of;
                 na.pre_out = c->preAB; na.n_lin_tiles = lin_tiles; na.ld_add = 8 * H; na.ld_out = 8 * H;
-                // helper waves: only the products the h2x attention of THIS layer needs (the first 4 H outputs, 256 KB of weights:
-                // what three helper waves can stream beside the node stage); the next layer's x2h products follow as a half-size
-                // node_linear launch
-                if (helpers > 0) na.n_lin_tiles = 4 * NT;
             }
             if (xc_fused) { if (launch_x2h_chain<H>(c, s, xea, na)) return 1; }
             else if (c->chain_bf16 && c->node_f16 && c->feat_f16) LAUNCH("node_chain", SMK((node_chain16_kernel<H, true>), dim3((n_ct + CHAIN_COLS - 1) / CHAIN_COLS), dim3(H * 4), Chain16Lds<H>::BYTES, s, na, c->status + ST_RANGE));
@@ -1005,9 +982,6 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             // per-node halves of the edge MLPs' first Linear: h2x of this layer | x2h of the next one
             if (!lin_fused && launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->P(Dl.lin6_img), c->P(Dl.lin16_img), c->addp + (size_t)l * c->capB * 8 * H, 8 * H,
                                  c->preAB, 8 * H, lin_tiles, n, (c->kstamp_sel == 0 && l == 0) ? c->kstamps : nullptr)) return 1;
-            if (helpers > 0 && lin_tiles > 4 * NT &&        // the second half: tiles 4 NT .. 8 NT - 1 (two-piece f16 image: 2 pieces x H / 32 k-steps x 256 words = 16 H words per tile)
-                launch_linear<H>(c, s, "node_pre", cur_h, c->P(Dl.lin_img), c->P(Dl.lin6_img), c->P(Dl.lin16_img) + (size_t)4 * NT * 16 * H,
-                                 c->addp + (size_t)l * c->capB * 8 * H + 4 * H, 8 * H, c->preAB + 4 * H, 8 * H, lin_tiles - 4 * NT, n, nullptr)) return 1;
         }
         float *x_next = (last && out_pos) ? out_pos : ((cur_x == c->x_a) ? c->x_b : c->x_a);
         bool vn_done = false, stats_done = false;
@@ -1288,7 +1262,6 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
         shapemol_ctx::GraphKey key{};
         key.N = N; key.B = B; key.guided = c->g_points > 0; key.fold = vn_fold_ok(c, (int)N);
         key.gfuse = c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap;
-        key.helpers = DISPATCH_H(c, lin_helper_waves<128>(c, (int)N, true), 0);
         // two executables: one reverse step, and kGraphUnroll steps back to back (the gap between two graph launches,
         // ~8 us, is then paid once per kGraphUnroll steps); every step reads its index from the device-side counter
         auto capture = [&](int n_steps, hipGraphExec_t *exec) -> int {
@@ -1344,11 +1317,6 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
         c->max_mol_atoms = (int)std::min<int64_t>(value, 1 << 20);
         return 0;
     }
-    if (k == "min_mol_atoms") {   // hint for the helper waves' term table (<= 4 molecules per workgroup); part of the graph key
-        if (value < 0) return fail("min_mol_atoms must be >= 0");
-        c->min_mol_atoms = (int)std::min<int64_t>(value, 1 << 20);
-        return 0;
-    }
     if (k == "first_step") {      // does not touch the captured graph: the step counter lives in device memory
         if (value < 0 || value >= c->cfg.num_timesteps) return fail("first_step must be in [0, num_timesteps)");
         c->first_step = (int)value;
@@ -1369,7 +1337,6 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     }
     else if (k == "lin_fuse") c->lin_fuse = value != 0;
     else if (k == "x2h_chain") c->x2h_chain = value != 0;
-    else if (k == "lin_helpers") c->lin_helpers = value != 0;
     else if (k == "graph_fuse") c->graph_fuse = value != 0;
     else if (k == "bn_eval") c->bn_eval = value != 0;
     else if (k == "ddpm_fold") c->ddpm_fold = value != 0;

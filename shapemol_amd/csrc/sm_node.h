@@ -314,10 +314,6 @@ struct NodeChainArgs {
     const int *mol_of;
     float *pre_out;
     int n_lin_tiles, ld_add, ld_out;
-    // x2h_chain16_kernel only: > 0 = that many HELPER waves (the waves beyond the H / 16 workers) compute those products beside
-    // the node stage, streaming the weight tiles through private LDS rings (sm_node16.h, lin_helper); 0 = separate launch
-    int lin_helpers;
-    int *span_flag;               // raised if a workgroup's columns span more molecules than the helpers' term table holds
 };
 
 // One workgroup = NT waves (one per 16-row block of output features) x CHAIN_COLS column tiles: every weight

@@ -177,162 +177,6 @@ struct Node16 {
     }
 };
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Per-node products of the next attentions computed by the HELPER waves of the fused x2h + node-stage kernel, beside the
-// node stage (round 3).  The products need 8 KB of weights per 16-row output tile, 512 KB per layer, and every workgroup must
-// stream all of it for its ~22 atoms: as a stage of the worker waves that cost 16 us (register-staged loads: 37 GB/s per CU,
-// tools/probes/weight_stream_probe.hip); here the waves that have nothing to do after the edge phase stream it by LDS-DMA
-// through PRIVATE rings while the workers run the node stage (3 issuing waves: 56 GB/s per CU in the probe):
-//   * helper hh owns tiles hh, hh + HW, ... and a ring of 2-3 slots of 8 KB behind the node stage's LDS; a slot holds one tile's
-//     A fragments exactly as the image stores them, so a tile is 8 DMA pieces of 1 KB;
-//   * no flags, no polling: a wave's vector-memory operations complete in order, so `s_waitcnt vmcnt(8 x (slots - 1))` means
-//     "my oldest tile has landed" (stores are not counted: a lower bound on the younger operations only makes the wait longer);
-//   * the compiler must not see LDS reads inside the loop (it would wait for EVERY outstanding LDS-DMA before each of them):
-//     the A fragments and the per-molecule terms are read by inline `ds_read_b128`, the h' fragments (B operand) are read once
-//     into registers when the workers have published them;
-//   * the helpers execute the same five `s_barrier`s as the workers (bare barriers: no counter drain), the first three while
-//     they only prefetch, the last two between tiles at points the workers reach no earlier;
-//   * the per-molecule term of an output tile (non-zero for the A blocks only) comes from an LDS table of the workgroup's <= 4
-//     molecules, filled by the helpers before the first of those barriers.
-// Same arithmetic in the same order as node_linear16_kernel (accumulator = term, then per 32-wide k-step lo*hi, hi*lo, hi*hi
-// on the fragments the node stage split from h'): bit-identical per-node products.
-constexpr int kLinHelperMols = 4;                    // molecules of the term table
-constexpr int kLinSlotBytes = 8192;                  // one tile of a two-piece f16 image at H = 128 (2 * NB * 64 * 16 bytes)
-constexpr int kLinRingSlots = 8;
-
-SM_DEV u32x4 lds_read16_asm(unsigned addr) {         // one 16-byte LDS read the compiler's waitcnt pass does not see
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-
-template <int H, bool P1>
-SM_DEV void lin_helper(const NodeChainArgs &a, int hh, int first_atom, int ncols, unsigned char *lds_base, bool follow) {
-    using L = Chain16Lds<H>;
-    constexpr int NB = H / 32, CC = CHAIN_COLS, NT = H / 16;
-    static_assert(2 * NB * 64 * 16 == kLinSlotBytes || H != 128, "slot = one tile of the image");
-    constexpr int TILE_U4 = 2 * NB * 64;                                  // u32x4 per tile of the image
-    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    const int HW = a.lin_helpers;
-    __builtin_amdgcn_s_setprio(3);      // the helpers are the youngest waves of their SIMDs: without priority the arbiter starves them
-    // ring: helper hh owns slots [s0, s0 + nslot) of the kLinRingSlots behind the node stage's buffers
-    const int s0 = hh * kLinRingSlots / HW, nslot = (hh + 1) * kLinRingSlots / HW - s0;
-    unsigned char *ring = lds_base + L::BYTES;
-    float *table = reinterpret_cast<float *>(ring + kLinRingSlots * kLinSlotBytes);      // [kLinHelperMols][4 H] terms of the A blocks
-    const int n_tiles = (a.n_lin_tiles - hh + HW - 1) / HW;                               // tiles hh, hh + HW, ...
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(1))) const void gbl_void;
-    auto issue_tile = [&](int i) {                     // tile hh + HW i -> slot i % nslot: 8 pieces of 1 KB
-        const int tile = hh + HW * i;
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.lin_img16) + (size_t)tile * TILE_U4 + lane;
-        unsigned char *dst = ring + (size_t)(s0 + i % nslot) * kLinSlotBytes;
-#pragma unroll
-        for (int p = 0; p < 2 * NB; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_void *)(src + p * 64), (lds_void *)(dst + p * 1024), 16, 0, 0);
-    };
-    // ---- the term table: rows of the workgroup's molecules, A blocks only (block index even), by all helper threads ----
-    const int last_atom = min(first_atom + ncols, a.n_atoms) - 1;
-    const int mol0 = a.mol_of[min(first_atom, a.n_atoms - 1)];
-    if (a.add_mol) {
-        const int nmol = a.mol_of[max(last_atom, 0)] - mol0 + 1;
-        if (nmol > kLinHelperMols && hh == 0 && lane == 0) *a.span_flag = 1;          // the min_mol_atoms hint was too large
-        const int n_blk = a.n_lin_tiles / NT;                                          // H-blocks of the output (8 or 4)
-        for (int it = hh * 64 + lane; it < kLinHelperMols * (n_blk / 2) * (H / 4); it += HW * 64) {
-            const int f4 = it % (H / 4), ab = (it / (H / 4)) % (n_blk / 2), m = it / ((H / 4) * (n_blk / 2));
-            float4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < nmol) v = ldg4(a.add_mol + (size_t)(mol0 + m) * a.ld_add + (2 * ab) * H + 4 * f4);
-            stg4(table + (m * (n_blk / 2) + ab) * H + 4 * f4, v);
-        }
-    }
-    int mslot[CC];
-    bool col_ok[CC];
-    size_t out_row[CC];
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-        const int at = min(first_atom + c * 16 + n, a.n_atoms - 1);
-        col_ok[c] = c * 16 + n < ncols && first_atom + c * 16 + n < a.n_atoms;
-        mslot[c] = min(max(a.mol_of[at] - mol0, 0), kLinHelperMols - 1);
-        out_row[c] = (size_t)at * a.ld_out;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (everything above is done before the first DMA piece; the table
-    for (int i = 0; i < nslot && i < n_tiles; ++i) issue_tile(i);  //  rows are in LDS before the barriers that publish them)
-    // ---- the workers' stage 1 (three barriers; h' fragments are complete after the third) -------------------------------
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_barrier();
-    if (!follow) {                                     // (no follow-up MLPs: the workers stop after stage 1's second barrier)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;                                        // (not reached by the fused launches, which always have a follow-up)
-    }
-    __builtin_amdgcn_s_barrier();
-    // (no compiler-visible LDS read from here on: with LDS-DMA pieces in flight the compiler would drain them before each one;
-    //  the h' fragments, like the weights and the terms, are read by inline ds_read_b128, two k-steps at a time: nothing but
-    //  the accumulators and a few addresses lives across an iteration, so nothing spills -- a scratch reload would be one more
-    //  vector-memory operation that waits for every DMA piece issued before it)
-    const unsigned ring_addr = (unsigned)(size_t)(lds_void *)ring, table_addr = (unsigned)(size_t)(lds_void *)table;
-    const unsigned fh_addr = (unsigned)(size_t)(lds_void *)(lds_base + (size_t)2 * L::FRAG * 16);
-    const int n_blk_half = a.n_lin_tiles / NT / 2;
-    // barrier points: after kB1 tiles (workers: follow-up first Linears, ~2 us) and kB1 + kB2 (normalise, ~1.5 us)
-    constexpr int kB1 = 4, kB2 = 3;
-    int barriers_left = 2;
-    for (int i = 0; i < n_tiles; ++i) {
-        if (barriers_left == 2 && i == kB1) { __builtin_amdgcn_s_barrier(); --barriers_left; }
-        if (barriers_left == 1 && i == kB1 + kB2) { __builtin_amdgcn_s_barrier(); --barriers_left; }
-        const int tile = hh + HW * i;
-        // tile i has landed when at most the (up to nslot - 1) younger tiles' pieces are outstanding
-        const int younger = min(nslot - 1, n_tiles - 1 - i);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned slot = ring_addr + (unsigned)((s0 + i % nslot) * kLinSlotBytes) + lane * 16;
-        // the tile's per-molecule term (A blocks: even H-block index)
-        const int blk = tile / NT;
-        f32x4 acc[CC];
-        u32x4 tv[CC];
-        const bool has_term = a.add_mol && (blk & 1) == 0;
-#pragma unroll
-        for (int c = 0; c < CC; ++c)
-            tv[c] = has_term ? lds_read16_asm(table_addr + (unsigned)(((mslot[c] * n_blk_half + (blk >> 1)) * H + 16 * (tile % NT) + 4 * g) * 4)) : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int half = 0; half < NB / 2; ++half) {
-            u32x4 w[2][2], xh[2][CC], xl[2][CC];
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const int b = 2 * half + bb;
-                w[0][bb] = lds_read16_asm(slot + (0 * NB + b) * 1024);
-                w[1][bb] = lds_read16_asm(slot + (1 * NB + b) * 1024);
-#pragma unroll
-                for (int c = 0; c < CC; ++c) {
-                    xh[bb][c] = lds_read16_asm(fh_addr + (unsigned)((((0 * NB + b) * CC + c) * 64 + frag_slot(b, lane)) * 16));
-                    xl[bb][c] = lds_read16_asm(fh_addr + (unsigned)((((1 * NB + b) * CC + c) * 64 + frag_slot(b, lane)) * 16));
-                }
-            }
-            // one wait for this half's LDS reads, tied to the registers they fill
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(xh[0][0]), "+v"(xh[0][1]), "+v"(xh[1][0]),
-                         "+v"(xh[1][1]), "+v"(xl[0][0]), "+v"(xl[0][1]), "+v"(xl[1][0]), "+v"(xl[1][1]), "+v"(tv[0]), "+v"(tv[1])::"memory");
-            if (half == 0) {
-#pragma unroll
-                for (int c = 0; c < CC; ++c) acc[c] = __builtin_bit_cast(f32x4, tv[c]);
-            }
-            if (half == NB / 2 - 1 && i + nslot < n_tiles) issue_tile(i + nslot);        // every fragment of the slot is in registers: refill it
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                if constexpr (!P1) {
-#pragma unroll
-                    for (int c = 0; c < CC; ++c) acc[c] = mfma_f16(w[1][bb], xh[bb][c], acc[c]);      // smallest terms first
-#pragma unroll
-                    for (int c = 0; c < CC; ++c) acc[c] = mfma_f16(w[0][bb], xl[bb][c], acc[c]);
-                }
-#pragma unroll
-                for (int c = 0; c < CC; ++c) acc[c] = mfma_f16(w[0][bb], xh[bb][c], acc[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CC; ++c)
-            if (col_ok[c]) stg4(a.pre_out + out_row[c] + 16 * tile + 4 * g, float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]});
-    }
-    while (barriers_left-- > 0) __builtin_amdgcn_s_barrier();      // (fewer tiles than barrier points)
-}
-
 // The node stage of a layer on the column block [first_atom, first_atom + ncols) (ncols <= 16 CC), waves 0 .. NT - 1 owning
 // one 16-row block of output features each.
 //   FUSED = false: the body of node_chain16_kernel (a workgroup of NT waves; [att | h] rows staged from global memory).
@@ -433,10 +277,7 @@ SM_DEV void chain16_body(const NodeChainArgs &a, int *range_flag, int first_atom
             dst[0] = hi; dst[2 * NB * CC * 64] = lo;
         }
         __syncthreads();
-        if (!worker) {
-            if (a.lin_helpers > 0 && ot - NT < a.lin_helpers) lin_helper<H, P1>(a, ot - NT, first_atom, ncols, chain16_lds, a.n_follow > 0);
-            return;
-        }
+        if (!worker) return;
     }
     SM_TICK(a.stamps, 1);
 

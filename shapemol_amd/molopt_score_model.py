@@ -411,11 +411,7 @@ class ScorePosNet3D(nn.Module):
                 seed = 0
         # the largest molecule of the batch lets the library fold the per-layer coordinate update into the next attention
         # kernel (one tiny synchronising reduction per chain; the reference synchronises at every step)
-        counts_ = torch.bincount(batch) if n else None
-        _lib.check(lib.shapemol_set_option(ctx, b"max_mol_atoms", int(counts_.max().item()) if n else 0), "shapemol_set_option")
-        # ... and the smallest one lets the helper waves of the fused x2h + node-stage launch compute the per-node products
-        # (their per-molecule term table holds four molecules per workgroup)
-        _lib.check(lib.shapemol_set_option(ctx, b"min_mol_atoms", int(counts_[counts_ > 0].min().item()) if n else 0), "shapemol_set_option")
+        _lib.check(lib.shapemol_set_option(ctx, b"max_mol_atoms", int(torch.bincount(batch).max().item()) if n else 0), "shapemol_set_option")
         gd = None
         if guided:
             cloud = np.ascontiguousarray(np.asarray(use_pointcloud_data[0], dtype=np.float64).reshape(-1, 3))

@@ -52,7 +52,6 @@ class ChainRunner:
         self.batch.copy_(torch.as_tensor(batch)); self.shape.copy_(torch.as_tensor(shape).reshape(self.b, -1, 3))
         counts = np.bincount(np.asarray(torch.as_tensor(batch).cpu()))
         _lib.check(_lib.load().shapemol_set_option(self.ctx, b"max_mol_atoms", int(counts.max()) if counts.size else 0), "shapemol_set_option")
-        _lib.check(_lib.load().shapemol_set_option(self.ctx, b"min_mol_atoms", int(counts[counts > 0].min()) if counts.size else 0), "shapemol_set_option")
 
     def set_noise(self, eps, u):
         """Host-fed noise for the whole chain (parity mode); None, None -> device Philox."""

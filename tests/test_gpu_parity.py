@@ -664,29 +664,6 @@ def test_forward_b1024_edge_tile_variants(tiles):
         assert maxabs(out[k], ref[k]) < FWD_TOL, k
 
 
-def test_helper_wave_products_equal_separate_launch():
-    """B = 256 chains: the per-node products computed by the helper waves of the fused x2h + node-stage launch (weight tiles
-    streamed through private LDS rings beside the node stage) against the separate node_linear16 launches: the same
-    arithmetic in the same order, so the chains must agree bit for bit -- also for a batch whose workgroups hold four
-    molecules (9-atom molecules), and with the mode switched off by a too small min_mol_atoms hint."""
-    m = hip_model()
-    for tag, kw in (("moses", dict()), ("small", dict(atoms_range=(9, 12)))):
-        bb = synth.synthetic_batch(256 if tag == "moses" else 500, seed=77, **kw)
-        S = 5
-        eps, u = hash_noise(len(bb["batch"]), S, 7)
-        res = {}
-        try:
-            for helpers in (1, 0):
-                m.set_option("lin_helpers", helpers)
-                r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
-                m.check_status()
-                res[helpers] = (r["pos"].cpu(), r["v"].cpu(), torch.stack(r["pos_cond_traj"]).cpu(), torch.stack(r["v_cond_traj"]).cpu())
-        finally:
-            m.set_option("lin_helpers", 1)
-        for x, y in zip(res[1], res[0]):
-            assert torch.equal(x, y), tag
-
-
 def test_chain_b1024_looping_edge_kernels_equal_sliced_launches():
     """A short chain at B = 1024 with the looping edge launches (edge_tiles = 1: eight waves per workgroup, consecutive jobs
     per workgroup, next job's rows prefetched; the coordinate update folded into the next x2h kernel over the workgroup's
