@@ -173,22 +173,23 @@ def _oracle_chain_against(c, steps, atoms_range=None, max_atoms=None, **model_kw
         assert maxabs(r["vt_traj"][-1], c["vt_last"]) < 1e-4
 
 
-# The CPU suite has to stay within a few minutes: by default these two run the first 11 / 21 reverse steps (three snapshots
-# each); SHAPEMOL_ORACLE_FULL=1 runs the fixtures' full 20 / 50 steps (measured once per round).
+# The CPU suite has to stay within a few minutes: by default these two run the first 6 / 11 reverse steps (two snapshots
+# each, ~25 s and ~70 s on 8 cores); SHAPEMOL_ORACLE_FULL=1 runs the fixtures' full 20 / 50 steps (run once per round:
+# profiles/r03/oracle_full_lengths.txt).
 _FULL = bool(int(__import__("os").environ.get("SHAPEMOL_ORACLE_FULL", "0")))
 
 
 def test_chain_k32_b64_oracle_golden():
     """The reference's 20-step chain at k = 32 (64 molecules of 40-80 atoms), snapshots every 5."""
     c = golden("chain_k32_b64_s20_hash.npz")
-    _oracle_chain_against(c, int(c["S"]) if _FULL else 11, atoms_range=(40, 80), seed=9, knn=32)
+    _oracle_chain_against(c, int(c["S"]) if _FULL else 6, atoms_range=(40, 80), seed=9, knn=32)
 
 
 def test_chain_b1024_s50_oracle_golden():
     """The reference's chain at the configs[2] / [3] per-GPU batch (1024 molecules, 21.9k atoms), snapshots every 10 (the
     oracle is the cpu_baseline of bench.py --batch 1024 and the checker of test_forward_b1024_vs_oracle)."""
     c = golden("chain_b1024_s50_hash.npz")
-    _oracle_chain_against(c, int(c["S"]) if _FULL else 21, max_atoms=38)
+    _oracle_chain_against(c, int(c["S"]) if _FULL else 11, max_atoms=38)
 
 
 # ---- the backward of the training step (SURVEY.md section 8 (f4), first milestone) ---------------------------------
