@@ -67,7 +67,7 @@ class HipMLP(torch.autograd.Function):
         rows, k_in, hidden, n_out = ctx.dims
         dev = x.device
         dy = dy.contiguous().float()
-        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
+        z = lambda *s: (torch.empty if rows > 0 else torch.zeros)(s, dtype=torch.float32, device=dev)  # noqa: E731  (the kernels overwrite)
         dx, dw1, db1, dg, dbe, dw2, db2 = z(rows, k_in), z(hidden, k_in), z(hidden), z(hidden), z(hidden), z(n_out, hidden), z(n_out)
         if rows > 0:
             lib = _lib.load()
@@ -109,7 +109,11 @@ def knn_edges(x, batch, k):
     inf = torch.tensor(float("inf"), device=x.device)
     d2 = torch.where(valid[:, None, :] & valid[:, :, None], d2, inf)
     d2 = torch.where(torch.eye(M, dtype=torch.bool, device=x.device)[None], inf, d2)
-    order = torch.sort(d2, dim=2, stable=True)[1][:, :, :min(k, M)]             # (B, M, k) local neighbour indices
+    # (B, M, k) local neighbour indices, ascending by (squared distance, index): topk on a key that breaks exact distance ties by
+    # the index (float32 distances are non-negative: their bit patterns order like integers; one kernel instead of the ~70
+    # merge passes of a stable sort of every row)
+    key = (d2.view(torch.int32).to(torch.int64) << 16) | torch.arange(M, device=x.device, dtype=torch.int64)[None, None, :]
+    order = torch.topk(key, min(k, M), dim=2, largest=False, sorted=True)[1]
     rank = torch.arange(order.shape[2], device=x.device)
     has = valid[:, :, None] & (rank[None, None, :] < (counts - 1).clamp(max=k)[:, None, None])
     src = (order + first[:, None, None])[has]
