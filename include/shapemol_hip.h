@@ -187,6 +187,17 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
                           const float *d_rstd, float *d_dx, float *d_dw1, float *d_db1, float *d_dgamma, float *d_dbeta,
                           float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream);
 
+/* The attention of one layer on the training path (models/uni_transformer.py:71-81 / :141-151): for every centre atom i, whose
+ * incoming edges are e in [ptr[i], ptr[i+1]) (edges grouped by centre), and head h: logits <q_i[h], k_e[h]> / sqrt(dh), softmax
+ * over the atom's edges, out_i[h][:] = sum_e alpha_e vals_e[h][:].  q (n_atoms, heads*dh), k (n_edges, heads*dh), vals
+ * (n_edges, heads, width) with width = dh (x2h) or 3 (h2x: value times relative position); dh, width <= 8.  _backward writes
+ * dq, dk, dvals (every edge belongs to exactly one atom: no accumulation, deterministic). */
+int shapemol_seg_attention_forward(const float *d_q, const float *d_k, const float *d_vals, const int64_t *d_ptr, int64_t n_atoms,
+                                   int32_t heads, int32_t dh, int32_t width, float *d_out, void *stream);
+int shapemol_seg_attention_backward(const float *d_q, const float *d_k, const float *d_vals, const int64_t *d_ptr, const float *d_dout,
+                                    int64_t n_atoms, int32_t heads, int32_t dh, int32_t width, float *d_dq, float *d_dk, float *d_dvals,
+                                    void *stream);
+
 /* ---- diagnostics (used by the parity tests and the bench; not needed by a caller) ---- */
 /* (options marked "_sample only" do not affect _score)
  * options: "first_step" (the following _sample calls resume a chain at reverse step v, i.e. at t = T-1-v, from the

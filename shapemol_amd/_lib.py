@@ -20,6 +20,7 @@ EXPORTS = (
     "shapemol_profile_begin", "shapemol_profile_end", "shapemol_status", "shapemol_status_stream", "shapemol_set_guidance", "shapemol_guide_points",
     "shapemol_pointcloud_guidance",
     "shapemol_mlp_backward_workspace", "shapemol_mlp_forward", "shapemol_mlp_backward",
+    "shapemol_seg_attention_forward", "shapemol_seg_attention_backward",
     "shapemol_set_bn_running",
     "shapemol_se_weight_count", "shapemol_se_create", "shapemol_se_destroy", "shapemol_se_encode",
 )
@@ -92,6 +93,8 @@ def load():
     lib.shapemol_mlp_backward_workspace.argtypes = [i64, i32, i32, i32]
     lib.shapemol_mlp_forward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.shapemol_mlp_backward.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.shapemol_seg_attention_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]
+    lib.shapemol_seg_attention_backward.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp]
     lib.shapemol_se_weight_count.restype = C.c_size_t
     lib.shapemol_se_weight_count.argtypes = [i32, i32, i32]
     lib.shapemol_se_create.argtypes = [i32, i32, i32, i32, vp, C.c_size_t, C.c_int, C.POINTER(vp)]

@@ -192,3 +192,77 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float *x, lon
         part[(size_t)blockIdx.x * cols + c] = (float)s;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Segment attention of the training path (models/uni_transformer.py:71-81 for x2h, :141-151 for h2x): for centre atom i with
+// incoming edges e in [ptr[i], ptr[i+1]) (edges grouped by centre, as the graph builder emits them) and head h
+//     logit_e = <q_i[h], k_e[h]> / sqrt(dh);   alpha = softmax over the atom's edges;   out_i[h][:] = sum_e alpha_e vals_e[h][:]
+// forward and backward in one pass each, one thread per (atom, head) (an atom has <= 32 edges; the backward recomputes the
+// softmax instead of storing alpha):  dvals_e = alpha_e dout_i;  dalpha_e = <dout_i, vals_e>;
+//     dlogit_e = alpha_e (dalpha_e - sum_e' alpha_e' dalpha_e');   dq_i = sum_e dlogit_e k_e / sqrt(dh);   dk_e = dlogit_e q_i / sqrt(dh).
+// q [N][heads dh], k [E][heads dh], vals [E][heads][W] (W = dh for x2h, 3 for h2x: value times relative position), W <= 8.
+struct SegAttnArgs {
+    const float *q, *k, *vals;
+    const long long *ptr;          // [N + 1]
+    float *out;                    // forward: [N][heads][W]
+    const float *dout;             // backward
+    float *dq, *dk, *dvals;
+    int n_atoms, heads, dh, W;
+};
+constexpr int kSegAttnMaxW = 8, kSegAttnMaxDh = 8;
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) seg_attention_kernel(SegAttnArgs a) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= a.n_atoms * a.heads) return;
+    const int i = gid / a.heads, h = gid % a.heads, H = a.heads * a.dh;
+    const long long e0 = a.ptr[i], e1 = a.ptr[i + 1];
+    const float scale = 1.0f / sqrtf((float)a.dh);
+    float qv[kSegAttnMaxDh];
+    for (int d = 0; d < a.dh; ++d) qv[d] = a.q[(size_t)i * H + h * a.dh + d];
+    // pass 1: maximum of the logits;  pass 2: sum of exponentials (and the forward's weighted sum)
+    float mx = -INFINITY;
+    for (long long e = e0; e < e1; ++e) {
+        float l = 0.f;
+        for (int d = 0; d < a.dh; ++d) l += qv[d] * a.k[(size_t)e * H + h * a.dh + d];
+        mx = fmaxf(mx, l * scale);
+    }
+    float den = 0.f, acc[kSegAttnMaxW];
+    for (int w = 0; w < a.W; ++w) acc[w] = 0.f;
+    for (long long e = e0; e < e1; ++e) {
+        float l = 0.f;
+        for (int d = 0; d < a.dh; ++d) l += qv[d] * a.k[(size_t)e * H + h * a.dh + d];
+        const float ex = expf(l * scale - mx);
+        den += ex;
+        if (!BWD)
+            for (int w = 0; w < a.W; ++w) acc[w] += ex * a.vals[((size_t)e * a.heads + h) * a.W + w];
+    }
+    if (!BWD) {
+        for (int w = 0; w < a.W; ++w) a.out[((size_t)i * a.heads + h) * a.W + w] = e1 > e0 ? acc[w] / den : 0.f;
+        return;
+    }
+    float dov[kSegAttnMaxW];
+    for (int w = 0; w < a.W; ++w) dov[w] = a.dout[((size_t)i * a.heads + h) * a.W + w];
+    // pass 3: s = sum_e alpha_e dalpha_e;  pass 4: the gradients
+    float s = 0.f;
+    for (long long e = e0; e < e1; ++e) {
+        float l = 0.f, da = 0.f;
+        for (int d = 0; d < a.dh; ++d) l += qv[d] * a.k[(size_t)e * H + h * a.dh + d];
+        for (int w = 0; w < a.W; ++w) da += dov[w] * a.vals[((size_t)e * a.heads + h) * a.W + w];
+        s += expf(l * scale - mx) / den * da;
+    }
+    float dqv[kSegAttnMaxDh];
+    for (int d = 0; d < a.dh; ++d) dqv[d] = 0.f;
+    for (long long e = e0; e < e1; ++e) {
+        float l = 0.f, da = 0.f;
+        for (int d = 0; d < a.dh; ++d) l += qv[d] * a.k[(size_t)e * H + h * a.dh + d];
+        for (int w = 0; w < a.W; ++w) da += dov[w] * a.vals[((size_t)e * a.heads + h) * a.W + w];
+        const float al = expf(l * scale - mx) / den, dl = al * (da - s) * scale;
+        for (int w = 0; w < a.W; ++w) a.dvals[((size_t)e * a.heads + h) * a.W + w] = al * dov[w];
+        for (int d = 0; d < a.dh; ++d) {
+            dqv[d] += dl * a.k[(size_t)e * H + h * a.dh + d];
+            a.dk[(size_t)e * H + h * a.dh + d] = dl * qv[d];
+        }
+    }
+    for (int d = 0; d < a.dh; ++d) a.dq[(size_t)i * H + h * a.dh + d] = dqv[d];
+}

@@ -118,4 +118,25 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
     return 0;
 }
 
+int shapemol_seg_attention_forward(const float *d_q, const float *d_k, const float *d_vals, const int64_t *d_ptr, int64_t n_atoms,
+                                   int32_t heads, int32_t dh, int32_t width, float *d_out, void *stream) {
+    if (!d_q || !d_k || !d_vals || !d_ptr || !d_out) return tr_fail("shapemol_seg_attention_forward: null argument");
+    if (n_atoms < 1 || heads < 1 || dh < 1 || dh > kSegAttnMaxDh || width < 1 || width > kSegAttnMaxW) return tr_fail("shapemol_seg_attention_forward: dimensions out of range (dh, width <= 8)");
+    SegAttnArgs a{d_q, d_k, d_vals, reinterpret_cast<const long long *>(d_ptr), d_out, nullptr, nullptr, nullptr, nullptr, (int)n_atoms, heads, dh, width};
+    hipLaunchKernelGGL(seg_attention_kernel<false>, dim3((unsigned)((n_atoms * heads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    TRCHK(hipGetLastError());
+    return 0;
+}
+
+int shapemol_seg_attention_backward(const float *d_q, const float *d_k, const float *d_vals, const int64_t *d_ptr, const float *d_dout,
+                                    int64_t n_atoms, int32_t heads, int32_t dh, int32_t width, float *d_dq, float *d_dk, float *d_dvals,
+                                    void *stream) {
+    if (!d_q || !d_k || !d_vals || !d_ptr || !d_dout || !d_dq || !d_dk || !d_dvals) return tr_fail("shapemol_seg_attention_backward: null argument");
+    if (n_atoms < 1 || heads < 1 || dh < 1 || dh > kSegAttnMaxDh || width < 1 || width > kSegAttnMaxW) return tr_fail("shapemol_seg_attention_backward: dimensions out of range (dh, width <= 8)");
+    SegAttnArgs a{d_q, d_k, d_vals, reinterpret_cast<const long long *>(d_ptr), nullptr, d_dout, d_dq, d_dk, d_dvals, (int)n_atoms, heads, dh, width};
+    hipLaunchKernelGGL(seg_attention_kernel<true>, dim3((unsigned)((n_atoms * heads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    TRCHK(hipGetLastError());
+    return 0;
+}
+
 }  // extern "C"

@@ -9,10 +9,13 @@ training step:
     the FLOPs of forward and backward) is ONE autograd node, :class:`HipMLP`, whose forward and backward are the HIP
     kernels of ``csrc/sm_train.h`` (fp32 MFMA products, deterministic reductions) behind ``shapemol_mlp_forward`` /
     ``shapemol_mlp_backward`` of the C ABI;
-  * the glue between them -- neighbour gathers, the segment softmax of the attention, scatter sums, the vector-neuron
-    linear / batch-norm / leaky-ReLU of the coordinate update, the two small Linears of the time embedding and of the
-    atom-type head -- is torch device ops recorded by autograd (the next milestones move them into HIP kernels with
-    hand-written backwards; the gate for each is ``tests/golden/grad_b12.npz``, the reference's own gradients).
+  * the attention of every layer (logits, segment softmax over an atom's edges, weighted sum: 16 per evaluation) is ONE
+    autograd node, :class:`HipSegAttention`, forward and backward in HIP (``seg_attention_kernel``: the softmax is
+    recomputed in the backward, every gradient entry is written by exactly one thread -- no atomics, deterministic);
+  * the glue between them -- neighbour gathers, the vector-neuron linear / batch-norm / leaky-ReLU of the coordinate update,
+    the two small Linears of the time embedding and of the atom-type head -- is torch device ops recorded by autograd (the
+    next milestones move them into HIP kernels with hand-written backwards; the gate for each is
+    ``tests/golden/grad_b12.npz``, the reference's own gradients).
 
 Reference semantics followed: ``models/molopt_score_model.py:286-320`` (forward), ``models/uni_transformer.py:48-90,
 121-162,181-189,446-540`` (layers, graph, shape embedding), ``models/shape_vn_layers.py:41-61,95-110`` (VN batch-norm in
@@ -81,6 +84,43 @@ class HipMLP(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None), dw1, db1, dg, dbe, dw2, db2
 
 
+class HipSegAttention(torch.autograd.Function):
+    """out_i[h] = sum_e softmax_e(<q_i[h], k_e[h]> / sqrt(dh)) vals_e[h] over the incoming edges e of atom i (edges grouped by
+    centre atom, ``ptr`` their CSR offsets); forward and backward are HIP kernels (csrc/sm_train.h, seg_attention_kernel)."""
+
+    @staticmethod
+    def forward(ctx, q, k, vals, ptr, heads):
+        if not q.is_cuda:
+            raise RuntimeError("HipSegAttention needs tensors on a HIP device (shapemol_amd has no CPU path)")
+        q, k, vals = q.contiguous().float(), k.contiguous().float(), vals.contiguous().float()
+        n, dh, width = q.shape[0], q.shape[1] // heads, vals.shape[2]
+        if ptr.dtype != torch.int64 or ptr.numel() != n + 1 or k.shape[0] != vals.shape[0] or vals.shape[1] != heads:
+            raise ValueError("HipSegAttention: ptr must be int64 of n_atoms + 1 entries, k and vals one row per edge")
+        out = (torch.empty if k.shape[0] > 0 else torch.zeros)((n, heads, width), dtype=torch.float32, device=q.device)
+        if n > 0 and k.shape[0] > 0:
+            with torch.cuda.device(q.device):
+                rc = _lib.load().shapemol_seg_attention_forward(_p(q), _p(k), _p(vals), _p(ptr), n, heads, dh, width, _p(out),
+                                                                C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+            _lib.check(rc, "shapemol_seg_attention_forward")
+        ctx.save_for_backward(q, k, vals, ptr)
+        ctx.dims = (n, heads, dh, width)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, vals, ptr = ctx.saved_tensors
+        n, heads, dh, width = ctx.dims
+        dout = dout.contiguous().float()
+        dq, dk, dvals = (torch.empty_like if k.shape[0] > 0 else torch.zeros_like)(q), torch.empty_like(k), torch.empty_like(vals)  # every entry is written
+        if n > 0 and k.shape[0] > 0:
+            with torch.cuda.device(q.device):
+                rc = _lib.load().shapemol_seg_attention_backward(_p(q), _p(k), _p(vals), _p(ptr), _p(dout), n, heads, dh, width,
+                                                                 _p(dq), _p(dk), _p(dvals),
+                                                                 C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+            _lib.check(rc, "shapemol_seg_attention_backward")
+        return dq, dk, dvals, None, None
+
+
 def _mlp(P, prefix, x):
     return HipMLP.apply(x, P[prefix + ".net.0.weight"], P[prefix + ".net.0.bias"], P[prefix + ".net.1.weight"], P[prefix + ".net.1.bias"],
                         P[prefix + ".net.3.weight"], P[prefix + ".net.3.bias"])
@@ -94,7 +134,7 @@ def _rbf(d):
 
 def knn_edges(x, batch, k):
     """Per-molecule k nearest neighbours on the device (self excluded; ties by (squared distance, index), the squared
-    distance evaluated as (dx*dx + dy*dy) + dz*dz like the sampling kernels): (src = j, dst = i), grouped by centre i."""
+    distance evaluated as (dx*dx + dy*dy) + dz*dz like the sampling kernels): (src = j, dst = i), grouped by centre i, and the CSR offsets of the groups (``batch`` sorted, as the reference's collate emits it)."""
     n = x.shape[0]
     counts = torch.bincount(batch)
     B, M = counts.shape[0], int(counts.max())
@@ -118,25 +158,9 @@ def knn_edges(x, batch, k):
     has = valid[:, :, None] & (rank[None, None, :] < (counts - 1).clamp(max=k)[:, None, None])
     src = (order + first[:, None, None])[has]
     dst = (torch.arange(M, device=x.device)[None, :, None] + first[:, None, None]).expand_as(order)[has]
-    return src, dst
-
-
-def _segment_softmax(logit, dst, n):
-    idx = dst.view(-1, 1).expand_as(logit)
-    mx = torch.full((n, logit.shape[1]), float("-inf"), device=logit.device).scatter_reduce(0, idx, logit.detach(), "amax", include_self=True)
-    ex = torch.exp(logit - mx[dst])
-    den = torch.zeros((n, logit.shape[1]), device=logit.device).index_add(0, dst, ex)
-    return ex / den[dst]
-
-
-def _segment_sum(val, dst, n):
-    return torch.zeros((n,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device).index_add(0, dst, val)
-
-
-def _attention(q, k, dst, n, heads):
-    dh = q.shape[1] // heads
-    logit = (q[dst].view(-1, heads, dh) * k.view(-1, heads, dh) / math.sqrt(dh)).sum(-1)
-    return _segment_softmax(logit, dst, n)
+    ptr = torch.zeros((n + 1,), dtype=torch.int64, device=x.device)
+    ptr[1:] = torch.cumsum(has.sum(2)[valid], 0)          # atoms in batch order == (molecule, local index) order
+    return src, dst, ptr
 
 
 def _vn_linear_lrelu(P, B, p, z, training):
@@ -184,7 +208,7 @@ def score_with_grad(model, pos, v, batch, shape, t):
     inv_atom = _mlp(P, "refine_net.invariant_shape_layer.hidden_layer", torch.einsum("bij,bj->bi", shape, m))[batch]
     shape_atom = shape[batch]
     x = pos
-    src, dst = knn_edges(x, batch, dm.k)
+    src, dst, ptr = knn_edges(x, batch, dm.k)
     e_w = torch.sigmoid(_mlp(P, "refine_net.edge_pred_layer", _rbf(torch.norm(x[dst] - x[src], p=2, dim=-1))))
     dh = dm.H // dm.heads
     for l in range(dm.L):
@@ -194,16 +218,14 @@ def score_with_grad(model, pos, v, batch, shape, t):
         # x2h (uni_transformer.py:48-90)
         px = p + ".x2h_layers.0"
         kv = torch.cat([rfeat, h[dst], h[src], inv_atom[dst]], -1)
-        alpha = _attention(_mlp(P, px + ".hq_func", h), _mlp(P, px + ".hk_func", kv), dst, n, dm.heads)
         val = (_mlp(P, px + ".hv_func", kv) * e_w.view(-1, 1)).view(-1, dm.heads, dh)
-        o = _segment_sum(alpha.unsqueeze(-1) * val, dst, n).view(n, dm.H)
+        o = HipSegAttention.apply(_mlp(P, px + ".hq_func", h), _mlp(P, px + ".hk_func", kv), val, ptr, dm.heads).view(n, dm.H)
         h = _mlp(P, px + ".node_output", torch.cat([o, h], -1)) + h
         # h2x (uni_transformer.py:121-162)
         ph = p + ".h2x_layers.0"
         kv = torch.cat([rfeat, h[dst], h[src], inv_atom[dst]], -1)
-        alpha = _attention(_mlp(P, ph + ".xq_func", h), _mlp(P, ph + ".xk_func", kv), dst, n, dm.heads)
         val = (_mlp(P, ph + ".xv_func", kv) * e_w.view(-1, 1)).unsqueeze(-1) * rel_x.unsqueeze(1)
-        o3 = _segment_sum(alpha.unsqueeze(-1) * val, dst, n)                         # (N, heads, 3)
+        o3 = HipSegAttention.apply(_mlp(P, ph + ".xq_func", h), _mlp(P, ph + ".xk_func", kv), val, ptr, dm.heads)   # (N, heads, 3)
         z = torch.cat((x.unsqueeze(1), o3, shape_atom), dim=1)
         x = x + o3.mean(dim=1) + _vn_linear_lrelu(P, Bf, ph + ".shape_linear", z, model.training).mean(dim=1)
     hv = F.softplus(lin("v_inference.0", h)) - math.log(2.0)

@@ -1102,6 +1102,41 @@ def test_hip_mlp_forward_backward_vs_torch_autograd(rows, k_in, hidden, n_out):
     assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("n_atoms,max_deg,width,seed", [(50, 8, 8, 0), (50, 8, 3, 1), (700, 32, 8, 2), (700, 32, 3, 3), (3, 1, 8, 4), (1, 0, 3, 5)])
+def test_hip_seg_attention_forward_backward_vs_torch_autograd(n_atoms, max_deg, width, seed):
+    """HipSegAttention (csrc/sm_train.h, seg_attention_kernel) against torch autograd of the reference's formulation
+    (models/uni_transformer.py:71-81: scatter_softmax of the scaled logits over the centre atom, scatter_sum of alpha * value)
+    in float64 on the device, on ragged graphs with 0 .. max_deg edges per atom (atoms without edges get zeros)."""
+    from shapemol_amd.training import HipSegAttention
+    heads, dh = 16, 8
+    g = torch.Generator().manual_seed(100 + seed)
+    deg = torch.randint(0, max_deg + 1, (n_atoms,), generator=g)
+    if n_atoms > 2:
+        deg[1] = 0                                          # an atom without incoming edges in the middle
+    ptr = torch.zeros(n_atoms + 1, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(deg, 0)
+    E = int(ptr[-1])
+    dst = torch.repeat_interleave(torch.arange(n_atoms), deg).to(DEV)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    q, k, vals, dout = mk(n_atoms, heads * dh) * 2, mk(E, heads * dh) * 2, mk(E, heads, width), mk(n_atoms, heads, width)
+    a = [t.clone().requires_grad_(True) for t in (q, k, vals)]
+    out = HipSegAttention.apply(a[0], a[1], a[2], ptr.to(DEV), heads)
+    out.backward(dout)
+    b = [t.double().clone().requires_grad_(True) for t in (q, k, vals)]
+    logit = (b[0][dst].view(-1, heads, dh) * b[1].view(-1, heads, dh) / np.sqrt(dh)).sum(-1)
+    idx = dst.view(-1, 1).expand_as(logit)
+    mx = torch.full((n_atoms, heads), float("-inf"), device=DEV, dtype=torch.float64).scatter_reduce(0, idx, logit.detach(), "amax")
+    ex = torch.exp(logit - mx[dst])
+    alpha = ex / torch.zeros((n_atoms, heads), device=DEV, dtype=torch.float64).index_add(0, dst, ex)[dst]
+    ref = torch.zeros((n_atoms, heads, width), device=DEV, dtype=torch.float64).index_add(0, dst, alpha.unsqueeze(-1) * b[2])
+    ref.backward(dout.double())
+    rel = lambda p, r: float((p.double() - r).abs().max() / r.abs().max().clamp(min=1e-6)) if r.numel() else 0.0  # noqa: E731
+    assert rel(out, ref) < 1e-5
+    errs = {nm: rel(p.grad, r.grad) for nm, p, r in zip(("dq", "dk", "dvals"), a, b)}
+    assert max(errs.values()) < 2e-5, errs
+    assert torch.isfinite(out).all() and all(torch.isfinite(t.grad).all() for t in a)
+
+
 def test_training_step_gradients_golden():
     """get_diffusion_loss with autograd enabled (the training step, scripts/train_diffusion.py:135-147) on the device: loss and
     the gradients of all 390 differentiated parameter tensors against the reference's own loss.backward() (grad_b12.npz),
