@@ -187,6 +187,25 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
                           const float *d_rstd, float *d_dx, float *d_dw1, float *d_db1, float *d_dgamma, float *d_dbeta,
                           float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream);
 
+/* The same block on edge rows whose input is the reference's concatenation [r_e | h_i | h_j | s_i] for edge e = (centre i = dst[e],
+ * neighbour j = src[e]) (models/uni_transformer.py:60-66 / :131-137: hk_func, hv_func, xk_func, xv_func): r (n_edges, k_edge) edge
+ * features, h (n_nodes, k_node) atom features, s (n_nodes, k_shape) per-atom shape embedding (k_shape may be 0, d_s NULL),
+ * W1 (hidden, k_edge + 2 k_node + k_shape) with the reference's column order.  The concatenated rows are never formed: the
+ * first Linear is evaluated as an edge term plus per-atom terms (pd, ps: (n_nodes, hidden) scratch), and the backward sums over
+ * each atom's edges before its per-atom products.  Edges must be grouped by centre atom (ptr_dst: n_nodes + 1 CSR offsets);
+ * perm_src / ptr_src list the edges grouped by neighbour atom (perm_src[t] = edge index).  Outputs and workspace as in
+ * shapemol_mlp_*; dW1 is written whole, dr / dh / ds are the gradients of r / h / s. */
+size_t shapemol_edge_mlp_backward_workspace(int64_t n_edges, int64_t n_nodes, int32_t k_edge, int32_t k_node, int32_t k_shape, int32_t hidden, int32_t n_out);
+int shapemol_edge_mlp_forward(const float *d_r, const float *d_h, const float *d_s, const int64_t *d_dst, const int64_t *d_src, int64_t n_edges,
+                              int64_t n_nodes, int32_t k_edge, int32_t k_node, int32_t k_shape, int32_t hidden, int32_t n_out, const float *d_w1,
+                              const float *d_b1, const float *d_gamma, const float *d_beta, const float *d_w2, const float *d_b2, float *d_y,
+                              float *d_xhat, float *d_rstd, float *d_act, float *d_pd, float *d_ps, void *stream);
+int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *d_s, const int64_t *d_ptr_dst, const int64_t *d_perm_src,
+                               const int64_t *d_ptr_src, const float *d_dy, int64_t n_edges, int64_t n_nodes, int32_t k_edge, int32_t k_node,
+                               int32_t k_shape, int32_t hidden, int32_t n_out, const float *d_w1, const float *d_gamma, const float *d_beta,
+                               const float *d_w2, const float *d_xhat, const float *d_rstd, float *d_dr, float *d_dh, float *d_ds, float *d_dw1,
+                               float *d_db1, float *d_dgamma, float *d_dbeta, float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream);
+
 /* The attention of one layer on the training path (models/uni_transformer.py:71-81 / :141-151): for every centre atom i, whose
  * incoming edges are e in [ptr[i], ptr[i+1]) (edges grouped by centre), and head h: logits <q_i[h], k_e[h]> / sqrt(dh), softmax
  * over the atom's edges, out_i[h][:] = sum_e alpha_e vals_e[h][:].  q (n_atoms, heads*dh), k (n_edges, heads*dh), vals

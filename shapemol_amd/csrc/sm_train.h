@@ -25,6 +25,7 @@ struct GemmArgs {
     int M, N, K;
     long long sam, sak, sbk, sbn;
     int ldc, kchunk;
+    int accum;                     // 1: C += (only with one split)
 };
 
 constexpr int kGemmKC = 16;
@@ -91,7 +92,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r;      // C/D fragment: row 4 g + r, column n
-                if (row < a.M && col < a.N) C[(size_t)row * a.ldc + col] = acc[i][j][r] + b;
+                if (row < a.M && col < a.N) {
+                    float *dst = C + (size_t)row * a.ldc + col;
+                    *dst = acc[i][j][r] + b + (a.accum ? *dst : 0.f);
+                }
             }
         }
 }
@@ -100,7 +104,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 // outputs, its 8 thread groups add every 8th partial (float64: partials of sums that cancel -- a bias in front of a
 // LayerNorm), the first group adds the 8 group sums.  (One thread per output walking all partials was a chain of up to 256
 // dependent loads: 27 % of a training step.)
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const float *part, int n_parts, long long n, float *out) {
+// The n outputs are a [n / cols][cols] matrix stored with row stride ldo (a column block of a wider gradient matrix).
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float *part, int n_parts, long long n, float *out, int cols, int ldo) {
     __shared__ double grp[8][32];
     const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
     const long long i = (long long)blockIdx.x * 32 + col;
@@ -113,19 +118,25 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float *part,
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += grp[k][col];
-        out[i] = (float)t;
+        out[(i / cols) * ldo + i % cols] = (float)t;
     }
 }
 
 // LayerNorm + ReLU of the rows of z [rows][H] (in place: z becomes the activation a), keeping xhat and rstd for the backward.
-// One wave per row, biased variance, two passes, as torch.nn.LayerNorm.
-__global__ void __launch_bounds__(256) ln_relu_fwd_kernel(float *z, const float *gamma, const float *beta, float *xhat, float *rstd, long long rows, int H) {
+// One wave per row, biased variance, two passes, as torch.nn.LayerNorm.  With pd / ps (the edge form, EdgeMLP below) row e first
+// receives the per-node terms of its two atoms: z[e] += pd[dst[e]] + ps[src[e]].
+__global__ void __launch_bounds__(256) ln_relu_fwd_kernel(float *z, const float *gamma, const float *beta, float *xhat, float *rstd, long long rows, int H,
+                                                          const float *pd, const float *ps, const long long *dst, const long long *src) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float *zr = z + row * H, *xr = xhat + row * H;
     float s = 0.f;
-    for (int c = lane; c < H; c += 64) s += zr[c];
+    if (pd) {
+        const float *pdr = pd + dst[row] * H, *psr = ps + src[row] * H;
+        for (int c = lane; c < H; c += 64) { const float v = zr[c] + (pdr[c] + psr[c]); zr[c] = v; s += v; }
+    } else
+        for (int c = lane; c < H; c += 64) s += zr[c];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s / H;
     float q = 0.f;
@@ -190,6 +201,21 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float *x, lon
         double s = 0.0;
         for (long long r = r0; r < r1; ++r) s += (double)x[r * cols + c];
         part[(size_t)blockIdx.x * cols + c] = (float)s;
+    }
+}
+
+// out[i][:] = sum of the rows x[perm ? perm[t] : t], t in [ptr[i], ptr[i+1]) -- the gradient of a per-node term that was gathered
+// to the edges (by centre atom: the edges are contiguous; by neighbour atom: through the permutation that groups them).
+// One wave per node, lanes over the columns; fixed order, no atomics.
+__global__ void __launch_bounds__(256) seg_rowsum_kernel(const float *x, const long long *ptr, const long long *perm, float *out, long long n_nodes, int H) {
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_nodes) return;
+    const long long t0 = ptr[i], t1 = ptr[i + 1];
+    for (int c = lane; c < H; c += 64) {
+        float s = 0.f;
+        for (long long t = t0; t < t1; ++t) s += x[(perm ? perm[t] : t) * H + c];
+        out[i * H + c] = s;
     }
 }
 

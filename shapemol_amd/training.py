@@ -9,6 +9,9 @@ training step:
     the FLOPs of forward and backward) is ONE autograd node, :class:`HipMLP`, whose forward and backward are the HIP
     kernels of ``csrc/sm_train.h`` (fp32 MFMA products, deterministic reductions) behind ``shapemol_mlp_forward`` /
     ``shapemol_mlp_backward`` of the C ABI;
+  * the four edge functions of every layer (key and value MLPs of x2h and h2x, 32 of the 58, whose input rows are the
+    concatenation [r_e | h_i | h_j | s_i]) are :class:`HipEdgeMLP`: the concatenation is never formed, the first Linear is
+    an edge term plus per-atom products as on the sampling path (``shapemol_edge_mlp_forward`` / ``_backward``);
   * the attention of every layer (logits, segment softmax over an atom's edges, weighted sum: 16 per evaluation) is ONE
     autograd node, :class:`HipSegAttention`, forward and backward in HIP (``seg_attention_kernel``: the softmax is
     recomputed in the backward, every gradient entry is written by exactly one thread -- no atomics, deterministic);
@@ -82,6 +85,72 @@ class HipMLP(torch.autograd.Function):
                                                _p(dw2), _p(db2), _p(work), n_work, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             _lib.check(rc, "shapemol_mlp_backward")
         return (dx if ctx.needs_input_grad[0] else None), dw1, db1, dg, dbe, dw2, db2
+
+
+class EdgeGraph:
+    """The kNN graph of one evaluation as the kernels want it: edges (src = neighbour j, dst = centre i) grouped by centre with
+    CSR offsets ``ptr``, and the same edges grouped by neighbour (``perm_src`` edge indices, ``ptr_src`` offsets) for the
+    gradient of terms gathered from the neighbour."""
+
+    def __init__(self, src, dst, ptr):
+        n = ptr.numel() - 1
+        self.src, self.dst, self.ptr = src.contiguous(), dst.contiguous(), ptr.contiguous()
+        self.perm_src = torch.sort(src, stable=True)[1].contiguous()
+        self.ptr_src = torch.zeros((n + 1,), dtype=torch.int64, device=src.device)
+        self.ptr_src[1:] = torch.cumsum(torch.bincount(src, minlength=n), 0)
+        self.n, self.E = n, src.numel()
+
+
+class HipEdgeMLP(torch.autograd.Function):
+    """The MLP block on the rows [r_e | h_i | h_j | s_i] of every edge e = (centre i, neighbour j) without forming them: the
+    first Linear is an edge term plus per-atom products (csrc/train_ops.hip, shapemol_edge_mlp_*); forward and backward in HIP."""
+
+    @staticmethod
+    def forward(ctx, r, h, s, graph, w1, b1, gamma, beta, w2, b2):
+        if not r.is_cuda:
+            raise RuntimeError("HipEdgeMLP needs tensors on a HIP device (shapemol_amd has no CPU path)")
+        r, h, s = r.contiguous().float(), h.contiguous().float(), s.contiguous().float()
+        ws = [t.detach().contiguous().float() for t in (w1, b1, gamma, beta, w2, b2)]
+        E, n = graph.E, graph.n
+        kr, kn, ks, hidden, n_out = r.shape[1], h.shape[1], s.shape[1], ws[0].shape[0], ws[4].shape[0]
+        if r.shape[0] != E or h.shape[0] != n or s.shape[0] != n or ws[0].shape[1] != kr + 2 * kn + ks:
+            raise ValueError("HipEdgeMLP: r is one row per edge, h and s one row per atom, W1 has k_edge + 2 k_node + k_shape columns")
+        new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=r.device)  # noqa: E731
+        y, xhat, rstd, act, pd, ps = new(E, n_out), new(E, hidden), new(E), new(E, hidden), new(n, hidden), new(n, hidden)
+        if E > 0:
+            with torch.cuda.device(r.device):
+                rc = _lib.load().shapemol_edge_mlp_forward(_p(r), _p(h), _p(s), _p(graph.dst), _p(graph.src), E, n, kr, kn, ks, hidden, n_out,
+                                                           *[_p(t) for t in ws], _p(y), _p(xhat), _p(rstd), _p(act), _p(pd), _p(ps),
+                                                           C.c_void_p(torch.cuda.current_stream(r.device).cuda_stream))
+            _lib.check(rc, "shapemol_edge_mlp_forward")
+        ctx.save_for_backward(r, h, s, ws[0], ws[2], ws[3], ws[4], xhat, rstd)
+        ctx.graph, ctx.dims = graph, (E, n, kr, kn, ks, hidden, n_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        r, h, s, w1, gamma, beta, w2, xhat, rstd = ctx.saved_tensors
+        E, n, kr, kn, ks, hidden, n_out = ctx.dims
+        g, dev = ctx.graph, r.device
+        dy = dy.contiguous().float()
+        z = lambda *sh: (torch.empty if E > 0 else torch.zeros)(sh, dtype=torch.float32, device=dev)  # noqa: E731  (the kernels overwrite)
+        dr, dh, ds = z(E, kr), z(n, kn), z(n, ks)
+        dw1, db1, dg, dbe, dw2, db2 = z(hidden, kr + 2 * kn + ks), z(hidden), z(hidden), z(hidden), z(n_out, hidden), z(n_out)
+        if E > 0:
+            lib = _lib.load()
+            n_work = lib.shapemol_edge_mlp_backward_workspace(E, n, kr, kn, ks, hidden, n_out)
+            work = torch.empty((n_work,), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.shapemol_edge_mlp_backward(_p(r), _p(h), _p(s), _p(g.ptr), _p(g.perm_src), _p(g.ptr_src), _p(dy), E, n, kr, kn, ks, hidden, n_out,
+                                                    _p(w1), _p(gamma), _p(beta), _p(w2), _p(xhat), _p(rstd), _p(dr), _p(dh), _p(ds), _p(dw1), _p(db1),
+                                                    _p(dg), _p(dbe), _p(dw2), _p(db2), _p(work), n_work, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(rc, "shapemol_edge_mlp_backward")
+        return dr, dh, ds, None, dw1, db1, dg, dbe, dw2, db2
+
+
+def _edge_mlp(P, prefix, r, h, s, graph):
+    return HipEdgeMLP.apply(r, h, s, graph, P[prefix + ".net.0.weight"], P[prefix + ".net.0.bias"], P[prefix + ".net.1.weight"],
+                            P[prefix + ".net.1.bias"], P[prefix + ".net.3.weight"], P[prefix + ".net.3.bias"])
 
 
 class HipSegAttention(torch.autograd.Function):
@@ -209,6 +278,7 @@ def score_with_grad(model, pos, v, batch, shape, t):
     shape_atom = shape[batch]
     x = pos
     src, dst, ptr = knn_edges(x, batch, dm.k)
+    graph = EdgeGraph(src, dst, ptr)
     e_w = torch.sigmoid(_mlp(P, "refine_net.edge_pred_layer", _rbf(torch.norm(x[dst] - x[src], p=2, dim=-1))))
     dh = dm.H // dm.heads
     for l in range(dm.L):
@@ -217,15 +287,13 @@ def score_with_grad(model, pos, v, batch, shape, t):
         rfeat = _rbf(torch.norm(rel_x, p=2, dim=-1))
         # x2h (uni_transformer.py:48-90)
         px = p + ".x2h_layers.0"
-        kv = torch.cat([rfeat, h[dst], h[src], inv_atom[dst]], -1)
-        val = (_mlp(P, px + ".hv_func", kv) * e_w.view(-1, 1)).view(-1, dm.heads, dh)
-        o = HipSegAttention.apply(_mlp(P, px + ".hq_func", h), _mlp(P, px + ".hk_func", kv), val, ptr, dm.heads).view(n, dm.H)
+        val = (_edge_mlp(P, px + ".hv_func", rfeat, h, inv_atom, graph) * e_w.view(-1, 1)).view(-1, dm.heads, dh)
+        o = HipSegAttention.apply(_mlp(P, px + ".hq_func", h), _edge_mlp(P, px + ".hk_func", rfeat, h, inv_atom, graph), val, ptr, dm.heads).view(n, dm.H)
         h = _mlp(P, px + ".node_output", torch.cat([o, h], -1)) + h
         # h2x (uni_transformer.py:121-162)
         ph = p + ".h2x_layers.0"
-        kv = torch.cat([rfeat, h[dst], h[src], inv_atom[dst]], -1)
-        val = (_mlp(P, ph + ".xv_func", kv) * e_w.view(-1, 1)).unsqueeze(-1) * rel_x.unsqueeze(1)
-        o3 = HipSegAttention.apply(_mlp(P, ph + ".xq_func", h), _mlp(P, ph + ".xk_func", kv), val, ptr, dm.heads)   # (N, heads, 3)
+        val = (_edge_mlp(P, ph + ".xv_func", rfeat, h, inv_atom, graph) * e_w.view(-1, 1)).unsqueeze(-1) * rel_x.unsqueeze(1)
+        o3 = HipSegAttention.apply(_mlp(P, ph + ".xq_func", h), _edge_mlp(P, ph + ".xk_func", rfeat, h, inv_atom, graph), val, ptr, dm.heads)   # (N, heads, 3)
         z = torch.cat((x.unsqueeze(1), o3, shape_atom), dim=1)
         x = x + o3.mean(dim=1) + _vn_linear_lrelu(P, Bf, ph + ".shape_linear", z, model.training).mean(dim=1)
     hv = F.softplus(lin("v_inference.0", h)) - math.log(2.0)

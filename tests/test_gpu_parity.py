@@ -1137,6 +1137,45 @@ def test_hip_seg_attention_forward_backward_vs_torch_autograd(n_atoms, max_deg, 
     assert torch.isfinite(out).all() and all(torch.isfinite(t.grad).all() for t in a)
 
 
+@pytest.mark.parametrize("n_atoms,max_deg,kr,kn,ks,hidden,n_out,seed", [(60, 8, 20, 128, 32, 128, 128, 0), (900, 32, 20, 128, 32, 128, 16, 1),
+                                                                         (40, 5, 7, 24, 0, 32, 8, 2), (2, 1, 20, 128, 32, 128, 128, 3)])
+def test_hip_edge_mlp_forward_backward_vs_torch_autograd(n_atoms, max_deg, kr, kn, ks, hidden, n_out, seed):
+    """HipEdgeMLP (the MLP block on [r_e | h_i | h_j | s_i] evaluated as an edge term plus per-atom products, csrc/train_ops.hip)
+    against torch autograd of the reference's formulation (models/uni_transformer.py:60-66: concatenate, then the MLP) in
+    float64 on the device: output and the gradients of r, h, s and all six parameter tensors, on ragged random graphs."""
+    from shapemol_amd.training import EdgeGraph, HipEdgeMLP
+    g = torch.Generator().manual_seed(200 + seed)
+    deg = torch.randint(1, max_deg + 1, (n_atoms,), generator=g)
+    if n_atoms > 2:
+        deg[1] = 0
+    ptr = torch.zeros(n_atoms + 1, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(deg, 0)
+    E = int(ptr[-1])
+    dst = torch.repeat_interleave(torch.arange(n_atoms), deg)
+    src = torch.randint(0, n_atoms, (E,), generator=g)
+    if n_atoms > 2:
+        src[src == 2] = 0                                    # an atom that is nobody's neighbour
+    graph = EdgeGraph(src.to(DEV), dst.to(DEV), ptr.to(DEV))
+    mk = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(DEV)  # noqa: E731
+    K1 = kr + 2 * kn + ks
+    ins = [mk(E, kr), mk(n_atoms, kn), mk(n_atoms, ks)]
+    ws = [mk(hidden, K1, sc=K1 ** -0.5), mk(hidden, sc=0.3), 1 + mk(hidden, sc=0.2), mk(hidden, sc=0.3), mk(n_out, hidden, sc=hidden ** -0.5), mk(n_out, sc=0.3)]
+    dy = mk(E, n_out)
+    a = [t.clone().requires_grad_(True) for t in ins + ws]
+    y = HipEdgeMLP.apply(a[0], a[1], a[2], graph, *a[3:])
+    y.backward(dy)
+    b = [t.double().clone().requires_grad_(True) for t in ins + ws]
+    kv = torch.cat([b[0], b[1][graph.dst], b[1][graph.src], b[2][graph.dst]], -1)
+    hh = torch.relu(torch.nn.functional.layer_norm(torch.nn.functional.linear(kv, b[3], b[4]), (hidden,), b[5], b[6], 1e-5))
+    yr = torch.nn.functional.linear(hh, b[7], b[8])
+    yr.backward(dy.double())
+    rel = lambda p, q: float((p.double() - q).abs().max() / q.abs().max().clamp(min=1e-6)) if q.numel() else 0.0  # noqa: E731
+    assert rel(y, yr) < 1e-5
+    names = ["dr", "dh", "ds", "dW1", "db1", "dgamma", "dbeta", "dW2", "db2"]
+    errs = {nm: rel(p.grad, q.grad) for nm, p, q in zip(names, a, b)}
+    assert max(errs.values()) < 1e-4, errs
+
+
 def test_training_step_gradients_golden():
     """get_diffusion_loss with autograd enabled (the training step, scripts/train_diffusion.py:135-147) on the device: loss and
     the gradients of all 390 differentiated parameter tensors against the reference's own loss.backward() (grad_b12.npz),
