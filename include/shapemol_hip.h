@@ -206,6 +206,24 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
                                const float *d_w2, const float *d_xhat, const float *d_rstd, float *d_dr, float *d_dh, float *d_ds, float *d_dw1,
                                float *d_db1, float *d_dgamma, float *d_dbeta, float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream);
 
+/* The coordinate update's vector-neuron block on the training path: VNLinearLeakyReLU with VNBatchNorm
+ * (models/shape_vn_layers.py:41-61, 95-110) applied to [x_n | o3_n | shape_mol(n)] and averaged over the output channels
+ * (models/uni_transformer.py:157-160).  x (n_atoms, 3), o3 (n_atoms, rows_o, 3), shape (n_molecules, rows_s, 3), batch (n_atoms)
+ * molecule index of every atom, wf / wd (channels, 1 + rows_o + rows_s), out (n_atoms, 3).  training != 0: batch statistics
+ * (running estimates, when given, updated with momentum 0.1 as nn.BatchNorm1d does); 0: the running estimates.  pf, dir
+ * (n_atoms, channels, 3) and stats (2, channels) are kept for the backward; nrm (n_atoms, channels) is scratch.  _backward: dx,
+ * do3, dw = dWf | dWd (2, channels, 1 + rows_o + rows_s), dbn_w, dbn_b from gout (n_atoms, 3); no gradient for shape (it comes
+ * from the frozen encoder). */
+size_t shapemol_vn_backward_workspace(int64_t n_atoms, int32_t rows_o, int32_t rows_s, int32_t channels);
+int shapemol_vn_forward(const float *d_x, const float *d_o3, const float *d_shape, const int64_t *d_batch, int64_t n_atoms, int32_t rows_o,
+                        int32_t rows_s, int32_t channels, const float *d_wf, const float *d_wd, const float *d_bn_w, const float *d_bn_b,
+                        float *d_run_mean, float *d_run_var, int32_t training, float *d_out, float *d_pf, float *d_dir, float *d_stats,
+                        float *d_nrm, void *stream);
+int shapemol_vn_backward(const float *d_x, const float *d_o3, const float *d_shape, const int64_t *d_batch, int64_t n_atoms, int32_t rows_o,
+                         int32_t rows_s, int32_t channels, const float *d_wf, const float *d_wd, const float *d_bn_w, const float *d_bn_b,
+                         const float *d_pf, const float *d_dir, const float *d_stats, int32_t training, const float *d_gout, float *d_dx,
+                         float *d_do3, float *d_dw, float *d_dbn_w, float *d_dbn_b, float *d_work, size_t work_floats, void *stream);
+
 /* The attention of one layer on the training path (models/uni_transformer.py:71-81 / :141-151): for every centre atom i, whose
  * incoming edges are e in [ptr[i], ptr[i+1]) (edges grouped by centre), and head h: logits <q_i[h], k_e[h]> / sqrt(dh), softmax
  * over the atom's edges, out_i[h][:] = sum_e alpha_e vals_e[h][:].  q (n_atoms, heads*dh), k (n_edges, heads*dh), vals

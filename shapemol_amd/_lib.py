@@ -21,6 +21,7 @@ EXPORTS = (
     "shapemol_pointcloud_guidance",
     "shapemol_mlp_backward_workspace", "shapemol_mlp_forward", "shapemol_mlp_backward",
     "shapemol_seg_attention_forward", "shapemol_seg_attention_backward",
+    "shapemol_vn_backward_workspace", "shapemol_vn_forward", "shapemol_vn_backward",
     "shapemol_edge_mlp_backward_workspace", "shapemol_edge_mlp_forward", "shapemol_edge_mlp_backward",
     "shapemol_set_bn_running",
     "shapemol_se_weight_count", "shapemol_se_create", "shapemol_se_destroy", "shapemol_se_encode",
@@ -98,6 +99,10 @@ def load():
     lib.shapemol_edge_mlp_backward_workspace.argtypes = [i64, i64, i32, i32, i32, i32, i32]
     lib.shapemol_edge_mlp_forward.argtypes = [vp] * 5 + [i64, i64] + [i32] * 5 + [vp] * 13
     lib.shapemol_edge_mlp_backward.argtypes = [vp] * 7 + [i64, i64] + [i32] * 5 + [vp] * 16 + [C.c_size_t, vp]
+    lib.shapemol_vn_backward_workspace.restype = C.c_size_t
+    lib.shapemol_vn_backward_workspace.argtypes = [i64, i32, i32, i32]
+    lib.shapemol_vn_forward.argtypes = [vp] * 4 + [i64, i32, i32, i32] + [vp] * 6 + [i32] + [vp] * 6
+    lib.shapemol_vn_backward.argtypes = [vp] * 4 + [i64, i32, i32, i32] + [vp] * 7 + [i32] + [vp] * 7 + [C.c_size_t, vp]
     lib.shapemol_seg_attention_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]
     lib.shapemol_seg_attention_backward.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp]
     lib.shapemol_se_weight_count.restype = C.c_size_t

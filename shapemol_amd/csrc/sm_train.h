@@ -292,3 +292,234 @@ __global__ void __launch_bounds__(256) seg_attention_kernel(SegAttnArgs a) {
     }
     for (int d = 0; d < a.dh; ++d) a.dq[(size_t)i * H + h * a.dh + d] = dqv[d];
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The coordinate update's vector-neuron block on the training path: VNLinearLeakyReLU with VNBatchNorm
+// (models/shape_vn_layers.py:41-61, 95-110) on z_n = [x_n | o3_n (rows_o rows) | shape_{mol(n)} (rows_s rows)], rows in R^3,
+// followed by the mean over the C output channels (models/uni_transformer.py:157-160):
+//     pf = Wf z;  nrm = |pf| + 1e-6;  nbn = BatchNorm_over_atoms(nrm) (train: batch mean / biased variance, eps 1e-5);
+//     p = pf nbn / nrm;  d = Wd z;  q = <p, d> / (|d|^2 + 1e-6);  y = p - 0.8 [<p, d> < 0] q d;  out_n = mean_c y
+// (0.2 p + 0.8 (p or p - q d) written as one expression).  Forward: vn_lin_kernel -> vn_bn_stats_kernel -> vn_act_kernel;
+// backward: vn_bwd_a_kernel (everything per (atom, channel) up to the batch-norm) -> vn_bwd_stats_kernel (the two batch sums of
+// the batch-norm's backward, its weight / bias gradients) -> vn_bwd_b_kernel (dpf, then dz = Wf^T dpf + Wd^T dd for the x and
+// o3 rows, and the workgroup's partial of dWf | dWd) -> reduce_partials_kernel.  One thread per (atom, channel), 256 / C atoms
+// per workgroup; every sum in a fixed order.
+struct VnTrainArgs {
+    const float *x, *o3, *shape;       // [N][3], [N][rows_o][3], [B][rows_s][3]
+    const long long *batch;            // [N]
+    const float *wf, *wd, *bn_w, *bn_b;   // [C][Cin] x 2, [C] x 2
+    float *run_mean, *run_var;         // [C] or null
+    float *pf, *dir, *nrm;             // [N][C][3] x 2, [N][C]
+    float *stats;                      // [2][C]: the mean and variance the normalisation used
+    float *out;                        // [N][3]
+    // backward
+    const float *gout;                 // [N][3]
+    float *dd, *dpfd, *dnd, *dnbn, *xhat;   // [N][C][3] x 2, [N][C] x 3
+    float *sums;                       // [2][C]: sum dnbn, sum dnbn xhat
+    float *dbn_w, *dbn_b;              // [C]
+    float *dx, *do3;                   // [N][3], [N][rows_o][3]
+    float *wpart;                      // [workgroups][2][C][Cin]
+    long long n_atoms;
+    int rows_o, rows_s, C, Cin, training;
+};
+constexpr float kVnEps = 1e-6f, kVnLeak = 0.2f, kBnEps = 1e-5f;
+
+__device__ __forceinline__ void vn_zrow(const VnTrainArgs &a, long long n, long long b, int i, float z[3]) {
+    const float *p = i == 0 ? a.x + n * 3 : i <= a.rows_o ? a.o3 + (n * a.rows_o + (i - 1)) * 3 : a.shape + (b * a.rows_s + (i - 1 - a.rows_o)) * 3;
+    z[0] = p[0]; z[1] = p[1]; z[2] = p[2];
+}
+
+__global__ void __launch_bounds__(256) vn_lin_kernel(VnTrainArgs a) {
+    extern __shared__ float vn_w[];                       // wf | wd
+    for (int i = threadIdx.x; i < 2 * a.C * a.Cin; i += 256) vn_w[i] = i < a.C * a.Cin ? a.wf[i] : a.wd[i - a.C * a.Cin];
+    __syncthreads();
+    const int per = 256 / a.C, la = threadIdx.x / a.C, c = threadIdx.x % a.C;
+    const long long n = (long long)blockIdx.x * per + la;
+    if (la >= per || n >= a.n_atoms) return;
+    const long long b = a.batch[n];
+    const float *wf = vn_w + c * a.Cin, *wd = vn_w + (a.C + c) * a.Cin;
+    float p[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < a.Cin; ++i) {
+        float z[3];
+        vn_zrow(a, n, b, i, z);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { p[k] += wf[i] * z[k]; d[k] += wd[i] * z[k]; }
+    }
+    const size_t o = ((size_t)n * a.C + c) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a.pf[o + k] = p[k]; a.dir[o + k] = d[k]; }
+    a.nrm[(size_t)n * a.C + c] = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + kVnEps;
+}
+
+__device__ __forceinline__ double vn_block_sum(double v, double *red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// grid = C: batch mean and biased variance of channel c (two passes, float64), running estimates updated as nn.BatchNorm1d
+// does (momentum 0.1, unbiased variance); evaluation mode: the running estimates are what the normalisation uses
+__global__ void __launch_bounds__(256) vn_bn_stats_kernel(VnTrainArgs a) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    if (!a.training) {
+        if (threadIdx.x == 0) { a.stats[c] = a.run_mean[c]; a.stats[a.C + c] = a.run_var[c]; }
+        return;
+    }
+    double s = 0.0;
+    for (long long n = threadIdx.x; n < a.n_atoms; n += 256) s += (double)a.nrm[n * a.C + c];
+    const double mean = vn_block_sum(s, red) / (double)a.n_atoms;
+    double q = 0.0;
+    for (long long n = threadIdx.x; n < a.n_atoms; n += 256) { const double d = (double)a.nrm[n * a.C + c] - mean; q += d * d; }
+    const double var = vn_block_sum(q, red) / (double)a.n_atoms;
+    if (threadIdx.x == 0) {
+        a.stats[c] = (float)mean;
+        a.stats[a.C + c] = (float)var;
+        if (a.run_mean) {
+            const double unb = var * (double)a.n_atoms / (double)(a.n_atoms > 1 ? a.n_atoms - 1 : 1);
+            a.run_mean[c] = 0.9f * a.run_mean[c] + 0.1f * (float)mean;
+            a.run_var[c] = 0.9f * a.run_var[c] + 0.1f * (float)unb;
+        }
+    }
+}
+
+// the per-(atom, channel) quantities both passes need
+struct VnPoint { float pf[3], d[3], p[3], nrm, xh, nbn, s, dot, dsq, q; bool neg; };
+__device__ __forceinline__ VnPoint vn_point(const VnTrainArgs &a, long long n, int c) {
+    VnPoint v;
+    const size_t o = ((size_t)n * a.C + c) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v.pf[k] = a.pf[o + k]; v.d[k] = a.dir[o + k]; }
+    v.nrm = sqrtf(v.pf[0] * v.pf[0] + v.pf[1] * v.pf[1] + v.pf[2] * v.pf[2]) + kVnEps;
+    const float rs = 1.0f / sqrtf(a.stats[a.C + c] + kBnEps);
+    v.xh = (v.nrm - a.stats[c]) * rs;
+    v.nbn = v.xh * a.bn_w[c] + a.bn_b[c];
+    v.s = v.nbn / v.nrm;
+    v.dot = 0.f; v.dsq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v.p[k] = v.pf[k] * v.s; v.dot += v.p[k] * v.d[k]; v.dsq += v.d[k] * v.d[k]; }
+    v.neg = !(v.dot >= 0.f);
+    v.q = v.dot / (v.dsq + kVnEps);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) vn_act_kernel(VnTrainArgs a) {
+    __shared__ float red[256][3];
+    const int per = 256 / a.C, la = threadIdx.x / a.C, c = threadIdx.x % a.C;
+    const long long n = (long long)blockIdx.x * per + la;
+    const bool ok = la < per && n < a.n_atoms;
+    float y[3] = {0.f, 0.f, 0.f};
+    if (ok) {
+        const VnPoint v = vn_point(a, n, c);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) y[k] = kVnLeak * v.p[k] + (1.f - kVnLeak) * (v.neg ? v.p[k] - v.q * v.d[k] : v.p[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) red[threadIdx.x][k] = y[k];
+    __syncthreads();
+    if (ok && c == 0) {
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < a.C; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[k] += red[la * a.C + j][k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.out[n * 3 + k] = s[k] / (float)a.C;
+    }
+}
+
+// dy = gout / C per channel.  y = p - 0.8 m q d (m = [dot < 0]):
+//   dp = dy - 0.8 m <dy, d> d / (dsq + eps);   dd = -0.8 m (q dy + <dy, d> (p - 2 q d) / (dsq + eps));
+//   p = pf s, s = nbn / nrm:  dpf (direct) = s dp;  ds = <dp, pf>;  dnbn = ds / nrm;  dnrm (direct) = -ds nbn / nrm^2
+__global__ void __launch_bounds__(256) vn_bwd_a_kernel(VnTrainArgs a) {
+    const int per = 256 / a.C, la = threadIdx.x / a.C, c = threadIdx.x % a.C;
+    const long long n = (long long)blockIdx.x * per + la;
+    if (la >= per || n >= a.n_atoms) return;
+    const VnPoint v = vn_point(a, n, c);
+    float dy[3], dyd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dy[k] = a.gout[n * 3 + k] / (float)a.C; dyd += dy[k] * v.d[k]; }
+    const float m = v.neg ? (1.f - kVnLeak) : 0.f, inv = 1.0f / (v.dsq + kVnEps);
+    float ds = 0.f;
+    const size_t o = ((size_t)n * a.C + c) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float dp = dy[k] - m * dyd * inv * v.d[k];
+        a.dd[o + k] = -m * (v.q * dy[k] + dyd * inv * (v.p[k] - 2.f * v.q * v.d[k]));
+        a.dpfd[o + k] = v.s * dp;
+        ds += dp * v.pf[k];
+    }
+    const size_t o1 = (size_t)n * a.C + c;
+    a.dnbn[o1] = ds / v.nrm;
+    a.dnd[o1] = -ds * v.nbn / (v.nrm * v.nrm);
+    a.xhat[o1] = v.xh;
+}
+
+// grid = C: S1 = sum_n dnbn, S2 = sum_n dnbn xhat (float64);  dbn_b = S1, dbn_w = S2
+__global__ void __launch_bounds__(256) vn_bwd_stats_kernel(VnTrainArgs a) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (long long n = threadIdx.x; n < a.n_atoms; n += 256) {
+        const double g = (double)a.dnbn[n * a.C + c];
+        s1 += g; s2 += g * (double)a.xhat[n * a.C + c];
+    }
+    s1 = vn_block_sum(s1, red);
+    s2 = vn_block_sum(s2, red);
+    if (threadIdx.x == 0) { a.sums[c] = (float)s1; a.sums[a.C + c] = (float)s2; a.dbn_b[c] = (float)s1; a.dbn_w[c] = (float)s2; }
+}
+
+// batch-norm backward (train: dnrm = rs g (dnbn - S1 / N - xhat S2 / N); eval: rs g dnbn), nrm = |pf| + eps -> dpf += dnrm pf / |pf|;
+// then the rows of dz this block's atoms own and the block's partial of dWf | dWd
+__global__ void __launch_bounds__(256) vn_bwd_b_kernel(VnTrainArgs a) {
+    extern __shared__ float vn_l[];                       // wf | wd [2][C][Cin], then dpf | dd [2][per][C][3]
+    const int per = 256 / a.C, la = threadIdx.x / a.C, c = threadIdx.x % a.C, WN = a.C * a.Cin;
+    float *w = vn_l, *g = vn_l + 2 * WN;
+    for (int i = threadIdx.x; i < 2 * WN; i += 256) w[i] = i < WN ? a.wf[i] : a.wd[i - WN];
+    const long long n0 = (long long)blockIdx.x * per, n = n0 + la;
+    const int n_here = (int)min((long long)per, a.n_atoms - n0);
+    if (la < per) {
+        float dpf[3] = {0.f, 0.f, 0.f}, dd[3] = {0.f, 0.f, 0.f};
+        if (n < a.n_atoms) {
+            const size_t o = ((size_t)n * a.C + c) * 3, o1 = (size_t)n * a.C + c;
+            const float rs = 1.0f / sqrtf(a.stats[a.C + c] + kBnEps);
+            const float cnt = (float)a.n_atoms;
+            float dn = a.dnbn[o1];
+            if (a.training) dn -= a.sums[c] / cnt + a.xhat[o1] * a.sums[a.C + c] / cnt;
+            const float dnrm = a.dnd[o1] + rs * a.bn_w[c] * dn;
+            const float p0 = a.pf[o], p1 = a.pf[o + 1], p2 = a.pf[o + 2];
+            const float len = fmaxf(sqrtf(p0 * p0 + p1 * p1 + p2 * p2), 1e-30f);
+            dpf[0] = a.dpfd[o] + dnrm * p0 / len; dpf[1] = a.dpfd[o + 1] + dnrm * p1 / len; dpf[2] = a.dpfd[o + 2] + dnrm * p2 / len;
+            dd[0] = a.dd[o]; dd[1] = a.dd[o + 1]; dd[2] = a.dd[o + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { g[(la * a.C + c) * 3 + k] = dpf[k]; g[((per + la) * a.C + c) * 3 + k] = dd[k]; }
+    }
+    __syncthreads();
+    // dz rows 0 .. rows_o of the block's atoms: dz[n][i][k] = sum_c wf[c][i] dpf[n][c][k] + wd[c][i] dd[n][c][k]
+    const int rows = 1 + a.rows_o;
+    for (int t = threadIdx.x; t < n_here * rows * 3; t += 256) {
+        const int at = t / (rows * 3), i = (t / 3) % rows, k = t % 3;
+        float s = 0.f;
+        for (int cc = 0; cc < a.C; ++cc) s += w[cc * a.Cin + i] * g[(at * a.C + cc) * 3 + k] + w[WN + cc * a.Cin + i] * g[((per + at) * a.C + cc) * 3 + k];
+        if (i == 0) a.dx[(n0 + at) * 3 + k] = s;
+        else a.do3[((n0 + at) * a.rows_o + (i - 1)) * 3 + k] = s;
+    }
+    // the block's partial of dWf | dWd: [mat][c][i] = sum over its atoms and the three components of (dpf | dd)[n][c] z[n][i]
+    for (int t = threadIdx.x; t < 2 * WN; t += 256) {
+        const int mat = t / WN, cc = (t % WN) / a.Cin, i = t % a.Cin;
+        float s = 0.f;
+        for (int at = 0; at < n_here; ++at) {
+            float z[3];
+            vn_zrow(a, n0 + at, a.batch[n0 + at], i, z);
+            const float *gg = g + ((mat * per + at) * a.C + cc) * 3;
+            s += gg[0] * z[0] + gg[1] * z[1] + gg[2] * z[2];
+        }
+        a.wpart[(size_t)blockIdx.x * 2 * WN + t] = s;
+    }
+}

@@ -105,9 +105,13 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
     // LayerNorm + ReLU backward: da -> dz in place, dgamma | dbeta partials
     hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nwg), dim3(256), (size_t)4 * 2 * H * sizeof(float), s, dz, d_xhat, d_rstd, d_gamma, d_beta, (long long)rows, H, pln);
     TRCHK(hipGetLastError());
-    if (reduce_parts(s, pln, nwg, 2 * H, gb)) return 1;
-    TRCHK(hipMemcpyAsync(d_dgamma, gb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    TRCHK(hipMemcpyAsync(d_dbeta, gb + H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (d_dbeta == d_dgamma + H) {                       // the caller's dgamma | dbeta are one array: reduce straight into it
+        if (reduce_parts(s, pln, nwg, 2 * H, d_dgamma)) return 1;
+    } else {
+        if (reduce_parts(s, pln, nwg, 2 * H, gb)) return 1;
+        TRCHK(hipMemcpyAsync(d_dgamma, gb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        TRCHK(hipMemcpyAsync(d_dbeta, gb + H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     // db1 = column sums of dz
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nwg), dim3(256), 0, s, dz, (long long)rows, H, pb1);
     TRCHK(hipGetLastError());
@@ -208,9 +212,13 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
     if (reduce_parts(s, part, sprE, (long long)n_out * Hd, d_dw2)) return 1;
     hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nwgE), dim3(256), (size_t)4 * 2 * Hd * sizeof(float), s, dz, d_xhat, d_rstd, d_gamma, d_beta, (long long)n_edges, Hd, pln);
     TRCHK(hipGetLastError());
-    if (reduce_parts(s, pln, nwgE, 2 * Hd, gb)) return 1;
-    TRCHK(hipMemcpyAsync(d_dgamma, gb, (size_t)Hd * sizeof(float), hipMemcpyDeviceToDevice, s));
-    TRCHK(hipMemcpyAsync(d_dbeta, gb + Hd, (size_t)Hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (d_dbeta == d_dgamma + Hd) {
+        if (reduce_parts(s, pln, nwgE, 2 * Hd, d_dgamma)) return 1;
+    } else {
+        if (reduce_parts(s, pln, nwgE, 2 * Hd, gb)) return 1;
+        TRCHK(hipMemcpyAsync(d_dgamma, gb, (size_t)Hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+        TRCHK(hipMemcpyAsync(d_dbeta, gb + Hd, (size_t)Hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     // the edge term: dWr = dz^T r (column block 0 of dW1), dr = dz Wr
     if (gemm(s, dz, 1, Hd, d_r, k_edge, 1, nullptr, part, k_edge, Hd, k_edge, E, spE)) return 1;
     if (reduce_parts(s, part, sprE, (long long)Hd * k_edge, d_dw1, k_edge, K1)) return 1;
@@ -234,6 +242,67 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
         if (gemm(s, dpd, Hd, 1, wi, K1, 1, nullptr, d_ds, k_shape, N, k_shape, Hd, 1)) return 1;                  // ds = dpd Wi
     }
     return 0;
+}
+
+// ---- the coordinate update's vector-neuron block (VNLinearLeakyReLU + VNBatchNorm + mean over channels), sm_train.h
+static bool bad_vn_dims(int64_t n, int rows_o, int rows_s, int C) {
+    return n < 1 || n > (1ll << 26) || rows_o < 0 || rows_o > 256 || rows_s < 0 || rows_s > 1024 || C < 1 || C > 64;
+}
+size_t shapemol_vn_backward_workspace(int64_t n_atoms, int32_t rows_o, int32_t rows_s, int32_t channels) {
+    if (bad_vn_dims(n_atoms, rows_o, rows_s, channels)) return 0;
+    const size_t NC = (size_t)n_atoms * channels, per = 256 / channels, nwg = ((size_t)n_atoms + per - 1) / per;
+    return 9 * NC + 2 * (size_t)channels + nwg * 2 * channels * (size_t)(1 + rows_o + rows_s) + 64;
+}
+
+int shapemol_vn_forward(const float *d_x, const float *d_o3, const float *d_shape, const int64_t *d_batch, int64_t n_atoms, int32_t rows_o,
+                        int32_t rows_s, int32_t channels, const float *d_wf, const float *d_wd, const float *d_bn_w, const float *d_bn_b,
+                        float *d_run_mean, float *d_run_var, int32_t training, float *d_out, float *d_pf, float *d_dir, float *d_stats,
+                        float *d_nrm, void *stream) {
+    if (!d_x || !d_batch || !d_wf || !d_wd || !d_bn_w || !d_bn_b || !d_out || !d_pf || !d_dir || !d_stats || !d_nrm || (rows_o > 0 && !d_o3) ||
+        (rows_s > 0 && !d_shape) || (!training && (!d_run_mean || !d_run_var)))
+        return tr_fail("shapemol_vn_forward: null argument");
+    if (bad_vn_dims(n_atoms, rows_o, rows_s, channels)) return tr_fail("shapemol_vn_forward: dimensions out of range (channels <= 64)");
+    hipStream_t s = (hipStream_t)stream;
+    VnTrainArgs a{};
+    a.x = d_x; a.o3 = d_o3; a.shape = d_shape; a.batch = reinterpret_cast<const long long *>(d_batch);
+    a.wf = d_wf; a.wd = d_wd; a.bn_w = d_bn_w; a.bn_b = d_bn_b; a.run_mean = d_run_mean; a.run_var = d_run_var;
+    a.pf = d_pf; a.dir = d_dir; a.nrm = d_nrm; a.stats = d_stats; a.out = d_out;
+    a.n_atoms = n_atoms; a.rows_o = rows_o; a.rows_s = rows_s; a.C = channels; a.Cin = 1 + rows_o + rows_s; a.training = training ? 1 : 0;
+    const int per = 256 / channels;
+    const unsigned nwg = (unsigned)((n_atoms + per - 1) / per);
+    hipLaunchKernelGGL(vn_lin_kernel, dim3(nwg), dim3(256), (size_t)2 * channels * a.Cin * sizeof(float), s, a);
+    hipLaunchKernelGGL(vn_bn_stats_kernel, dim3(channels), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(vn_act_kernel, dim3(nwg), dim3(256), 0, s, a);
+    TRCHK(hipGetLastError());
+    return 0;
+}
+
+int shapemol_vn_backward(const float *d_x, const float *d_o3, const float *d_shape, const int64_t *d_batch, int64_t n_atoms, int32_t rows_o,
+                         int32_t rows_s, int32_t channels, const float *d_wf, const float *d_wd, const float *d_bn_w, const float *d_bn_b,
+                         const float *d_pf, const float *d_dir, const float *d_stats, int32_t training, const float *d_gout, float *d_dx,
+                         float *d_do3, float *d_dw, float *d_dbn_w, float *d_dbn_b, float *d_work, size_t work_floats, void *stream) {
+    if (!d_x || !d_batch || !d_wf || !d_wd || !d_bn_w || !d_bn_b || !d_pf || !d_dir || !d_stats || !d_gout || !d_dx || !d_dw || !d_dbn_w || !d_dbn_b ||
+        !d_work || (rows_o > 0 && (!d_o3 || !d_do3)) || (rows_s > 0 && !d_shape))
+        return tr_fail("shapemol_vn_backward: null argument");
+    if (bad_vn_dims(n_atoms, rows_o, rows_s, channels)) return tr_fail("shapemol_vn_backward: dimensions out of range (channels <= 64)");
+    if (work_floats < shapemol_vn_backward_workspace(n_atoms, rows_o, rows_s, channels)) return tr_fail("shapemol_vn_backward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t NC = (size_t)n_atoms * channels;
+    const int per = 256 / channels, Cin = 1 + rows_o + rows_s;
+    const unsigned nwg = (unsigned)((n_atoms + per - 1) / per);
+    VnTrainArgs a{};
+    a.x = d_x; a.o3 = d_o3; a.shape = d_shape; a.batch = reinterpret_cast<const long long *>(d_batch);
+    a.wf = d_wf; a.wd = d_wd; a.bn_w = d_bn_w; a.bn_b = d_bn_b;
+    a.pf = const_cast<float *>(d_pf); a.dir = const_cast<float *>(d_dir); a.stats = const_cast<float *>(d_stats);
+    a.gout = d_gout;
+    a.dd = d_work; a.dpfd = a.dd + 3 * NC; a.dnd = a.dpfd + 3 * NC; a.dnbn = a.dnd + NC; a.xhat = a.dnbn + NC; a.sums = a.xhat + NC; a.wpart = a.sums + 2 * channels;
+    a.dbn_w = d_dbn_w; a.dbn_b = d_dbn_b; a.dx = d_dx; a.do3 = d_do3;
+    a.n_atoms = n_atoms; a.rows_o = rows_o; a.rows_s = rows_s; a.C = channels; a.Cin = Cin; a.training = training ? 1 : 0;
+    hipLaunchKernelGGL(vn_bwd_a_kernel, dim3(nwg), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(vn_bwd_stats_kernel, dim3(channels), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(vn_bwd_b_kernel, dim3(nwg), dim3(256), ((size_t)2 * channels * Cin + (size_t)2 * per * channels * 3) * sizeof(float), s, a);
+    TRCHK(hipGetLastError());
+    return reduce_parts(s, a.wpart, (int)nwg, (long long)2 * channels * Cin, d_dw);        // dWf | dWd
 }
 
 int shapemol_seg_attention_forward(const float *d_q, const float *d_k, const float *d_vals, const int64_t *d_ptr, int64_t n_atoms,

@@ -15,10 +15,13 @@ training step:
   * the attention of every layer (logits, segment softmax over an atom's edges, weighted sum: 16 per evaluation) is ONE
     autograd node, :class:`HipSegAttention`, forward and backward in HIP (``seg_attention_kernel``: the softmax is
     recomputed in the backward, every gradient entry is written by exactly one thread -- no atomics, deterministic);
-  * the glue between them -- neighbour gathers, the vector-neuron linear / batch-norm / leaky-ReLU of the coordinate update,
-    the two small Linears of the time embedding and of the atom-type head -- is torch device ops recorded by autograd (the
-    next milestones move them into HIP kernels with hand-written backwards; the gate for each is
-    ``tests/golden/grad_b12.npz``, the reference's own gradients).
+  * the coordinate update's vector-neuron block (VN-linear, train-mode batch-norm over the atoms, VN-leaky-ReLU, mean over
+    the channels: 8 per evaluation) is ONE autograd node, :class:`HipVN` (``vn_*_kernel``; the batch statistics and the
+    batch-norm's backward sums are two-pass float64 reductions in a fixed order);
+  * what is left in torch device ops recorded by autograd: the kNN graph, the Gaussian smearing of the distances, the
+    products with the edge weights and relative positions, the residual sums, the small Linears of the time / atom
+    embedding and of the atom-type head (the gate for moving each is ``tests/golden/grad_b12.npz``, the reference's own
+    gradients).
 
 Reference semantics followed: ``models/molopt_score_model.py:286-320`` (forward), ``models/uni_transformer.py:48-90,
 121-162,181-189,446-540`` (layers, graph, shape embedding), ``models/shape_vn_layers.py:41-61,95-110`` (VN batch-norm in
@@ -35,7 +38,6 @@ from . import _lib
 from .spec import RBF_CENTRES
 
 VN_EPS = 1e-6
-LEAK = 0.2
 
 
 def _p(t):
@@ -74,7 +76,8 @@ class HipMLP(torch.autograd.Function):
         dev = x.device
         dy = dy.contiguous().float()
         z = lambda *s: (torch.empty if rows > 0 else torch.zeros)(s, dtype=torch.float32, device=dev)  # noqa: E731  (the kernels overwrite)
-        dx, dw1, db1, dg, dbe, dw2, db2 = z(rows, k_in), z(hidden, k_in), z(hidden), z(hidden), z(hidden), z(n_out, hidden), z(n_out)
+        dx, dw1, db1, gb, dw2, db2 = z(rows, k_in), z(hidden, k_in), z(hidden), z(2 * hidden), z(n_out, hidden), z(n_out)
+        dg, dbe = gb[:hidden], gb[hidden:]               # one array: the library reduces dgamma | dbeta into it in one launch
         if rows > 0:
             lib = _lib.load()
             n_work = lib.shapemol_mlp_backward_workspace(rows, k_in, hidden, n_out)
@@ -135,7 +138,8 @@ class HipEdgeMLP(torch.autograd.Function):
         dy = dy.contiguous().float()
         z = lambda *sh: (torch.empty if E > 0 else torch.zeros)(sh, dtype=torch.float32, device=dev)  # noqa: E731  (the kernels overwrite)
         dr, dh, ds = z(E, kr), z(n, kn), z(n, ks)
-        dw1, db1, dg, dbe, dw2, db2 = z(hidden, kr + 2 * kn + ks), z(hidden), z(hidden), z(hidden), z(n_out, hidden), z(n_out)
+        dw1, db1, gb, dw2, db2 = z(hidden, kr + 2 * kn + ks), z(hidden), z(2 * hidden), z(n_out, hidden), z(n_out)
+        dg, dbe = gb[:hidden], gb[hidden:]
         if E > 0:
             lib = _lib.load()
             n_work = lib.shapemol_edge_mlp_backward_workspace(E, n, kr, kn, ks, hidden, n_out)
@@ -190,6 +194,51 @@ class HipSegAttention(torch.autograd.Function):
         return dq, dk, dvals, None, None
 
 
+class HipVN(torch.autograd.Function):
+    """mean over the output channels of VNLinearLeakyReLU (with VNBatchNorm) applied to [x_n | o3_n | shape_mol(n)]
+    (models/shape_vn_layers.py:41-61,95-110; uni_transformer.py:157-160): forward and backward in HIP (csrc/sm_train.h, vn_*)."""
+
+    @staticmethod
+    def forward(ctx, x, o3, shape, batch, wf, wd, bn_w, bn_b, run_mean, run_var, training):
+        if not x.is_cuda:
+            raise RuntimeError("HipVN needs tensors on a HIP device (shapemol_amd has no CPU path)")
+        if shape.requires_grad:
+            raise NotImplementedError("HipVN: no gradient for the shape embedding (it comes from the frozen encoder)")
+        x, o3, shape = x.contiguous().float(), o3.contiguous().float(), shape.contiguous().float()
+        ws = [t.detach().contiguous().float() for t in (wf, wd, bn_w, bn_b)]
+        n, rows_o, rows_s, ch = x.shape[0], o3.shape[1], shape.shape[1], ws[0].shape[0]
+        if ws[0].shape[1] != 1 + rows_o + rows_s or run_mean.dtype != torch.float32 or not run_mean.is_contiguous() or not run_var.is_contiguous():
+            raise ValueError("HipVN: the VN weights have 1 + rows_o + rows_s columns; running statistics are contiguous float32")
+        new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=x.device)  # noqa: E731
+        out, pf, dr, stats, nrm = new(n, 3), new(n, ch, 3), new(n, ch, 3), new(2, ch), new(n, ch)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().shapemol_vn_forward(_p(x), _p(o3), _p(shape), _p(batch), n, rows_o, rows_s, ch, *[_p(t) for t in ws], _p(run_mean), _p(run_var),
+                                                 int(bool(training)), _p(out), _p(pf), _p(dr), _p(stats), _p(nrm),
+                                                 C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        _lib.check(rc, "shapemol_vn_forward")
+        ctx.save_for_backward(x, o3, shape, batch, *ws, pf, dr, stats)
+        ctx.dims = (n, rows_o, rows_s, ch, int(bool(training)))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, o3, shape, batch, wf, wd, bn_w, bn_b, pf, dr, stats = ctx.saved_tensors
+        n, rows_o, rows_s, ch, training = ctx.dims
+        dev = x.device
+        gout = gout.contiguous().float()
+        new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
+        dx, do3, dw, dg, db = new(n, 3), new(n, rows_o, 3), new(2, ch, 1 + rows_o + rows_s), new(ch), new(ch)
+        lib = _lib.load()
+        n_work = lib.shapemol_vn_backward_workspace(n, rows_o, rows_s, ch)
+        work = new(n_work)
+        with torch.cuda.device(dev):
+            rc = lib.shapemol_vn_backward(_p(x), _p(o3), _p(shape), _p(batch), n, rows_o, rows_s, ch, _p(wf), _p(wd), _p(bn_w), _p(bn_b), _p(pf), _p(dr),
+                                          _p(stats), training, _p(gout), _p(dx), _p(do3), _p(dw), _p(dg), _p(db), _p(work), n_work,
+                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "shapemol_vn_backward")
+        return dx, do3, None, None, dw[0], dw[1], dg, db, None, None, None
+
+
 def _mlp(P, prefix, x):
     return HipMLP.apply(x, P[prefix + ".net.0.weight"], P[prefix + ".net.0.bias"], P[prefix + ".net.1.weight"], P[prefix + ".net.1.bias"],
                         P[prefix + ".net.3.weight"], P[prefix + ".net.3.bias"])
@@ -232,29 +281,13 @@ def knn_edges(x, batch, k):
     return src, dst, ptr
 
 
-def _vn_linear_lrelu(P, B, p, z, training):
-    """VNLinearLeakyReLU with VNBatchNorm (models/shape_vn_layers.py:41-61,95-110); z (N, Cin, 3) -> (N, Cout, 3)."""
-    wf, wd = P[p + ".map_to_feat.weight"], P[p + ".map_to_dir.weight"]
-    pf = torch.einsum("oc,ncd->nod", wf, z)
-    nrm = torch.sqrt((pf * pf).sum(2)) + VN_EPS
-    rm, rv = B[p + ".batchnorm.bn.running_mean"], B[p + ".batchnorm.bn.running_var"]
+def _vn_update(P, B, p, x, o3, shape, batch, training):
+    """mean_c VNLinearLeakyReLU([x | o3 | shape[batch]]) -> (N, 3); train mode also updates the running statistics."""
+    out = HipVN.apply(x, o3, shape, batch, P[p + ".map_to_feat.weight"], P[p + ".map_to_dir.weight"], P[p + ".batchnorm.bn.weight"],
+                      P[p + ".batchnorm.bn.bias"], B[p + ".batchnorm.bn.running_mean"], B[p + ".batchnorm.bn.running_var"], training)
     if training:
-        mean = nrm.mean(0)
-        var = ((nrm - mean) ** 2).mean(0)
-        with torch.no_grad():      # nn.BatchNorm1d in train mode: momentum 0.1, unbiased variance into the running estimate
-            cnt = nrm.shape[0]
-            rm.mul_(0.9).add_(0.1 * mean.detach())
-            rv.mul_(0.9).add_(0.1 * var.detach() * (cnt / max(cnt - 1, 1)))
-            B[p + ".batchnorm.bn.num_batches_tracked"].add_(1)
-    else:
-        mean, var = rm, rv
-    nbn = (nrm - mean) / torch.sqrt(var + 1e-5) * P[p + ".batchnorm.bn.weight"] + P[p + ".batchnorm.bn.bias"]
-    pf = pf / nrm.unsqueeze(2) * nbn.unsqueeze(2)
-    d = torch.einsum("oc,ncd->nod", wd, z)
-    dot = (pf * d).sum(2, keepdim=True)
-    mask = (dot >= 0).float()
-    dsq = (d * d).sum(2, keepdim=True)
-    return LEAK * pf + (1 - LEAK) * (mask * pf + (1 - mask) * (pf - (dot / (dsq + VN_EPS)) * d))
+        B[p + ".batchnorm.bn.num_batches_tracked"].add_(1)
+    return out
 
 
 def score_with_grad(model, pos, v, batch, shape, t):
@@ -275,7 +308,6 @@ def score_with_grad(model, pos, v, batch, shape, t):
     m = shape.mean(dim=1)
     m = m / ((m * m).sum(-1, keepdim=True) + VN_EPS)
     inv_atom = _mlp(P, "refine_net.invariant_shape_layer.hidden_layer", torch.einsum("bij,bj->bi", shape, m))[batch]
-    shape_atom = shape[batch]
     x = pos
     src, dst, ptr = knn_edges(x, batch, dm.k)
     graph = EdgeGraph(src, dst, ptr)
@@ -294,7 +326,6 @@ def score_with_grad(model, pos, v, batch, shape, t):
         ph = p + ".h2x_layers.0"
         val = (_edge_mlp(P, ph + ".xv_func", rfeat, h, inv_atom, graph) * e_w.view(-1, 1)).unsqueeze(-1) * rel_x.unsqueeze(1)
         o3 = HipSegAttention.apply(_mlp(P, ph + ".xq_func", h), _edge_mlp(P, ph + ".xk_func", rfeat, h, inv_atom, graph), val, ptr, dm.heads)   # (N, heads, 3)
-        z = torch.cat((x.unsqueeze(1), o3, shape_atom), dim=1)
-        x = x + o3.mean(dim=1) + _vn_linear_lrelu(P, Bf, ph + ".shape_linear", z, model.training).mean(dim=1)
+        x = x + o3.mean(dim=1) + _vn_update(P, Bf, ph + ".shape_linear", x, o3, shape, batch, model.training)
     hv = F.softplus(lin("v_inference.0", h)) - math.log(2.0)
     return {"pred_ligand_pos": x, "pred_ligand_h": h, "pred_ligand_v": lin("v_inference.2", hv)}

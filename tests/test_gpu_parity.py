@@ -1176,6 +1176,53 @@ def test_hip_edge_mlp_forward_backward_vs_torch_autograd(n_atoms, max_deg, kr, k
     assert max(errs.values()) < 1e-4, errs
 
 
+@pytest.mark.parametrize("n_mol,rows_o,rows_s,ch,training,seed", [(12, 16, 32, 16, True, 0), (12, 16, 32, 16, False, 1), (200, 16, 32, 16, True, 2),
+                                                                  (5, 3, 4, 8, True, 3), (1, 16, 32, 16, True, 4)])
+def test_hip_vn_forward_backward_vs_torch_autograd(n_mol, rows_o, rows_s, ch, training, seed):
+    """HipVN (csrc/sm_train.h, vn_*_kernel) against torch autograd of the reference's formulation (models/shape_vn_layers.py:
+    41-61, 95-110 + the mean over channels, uni_transformer.py:157-160) in float64 on the device: output, the gradients of x,
+    o3, both VN weights and the batch-norm's affine pair, and the running statistics a training-mode call leaves behind."""
+    from shapemol_amd.training import HipVN
+    g = torch.Generator().manual_seed(300 + seed)
+    counts = torch.randint(9, 28, (n_mol,), generator=g)
+    batch = torch.repeat_interleave(torch.arange(n_mol), counts).to(DEV)
+    n, cin = int(counts.sum()), 1 + rows_o + rows_s
+    mk = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(DEV)  # noqa: E731
+    x, o3, shape = mk(n, 3), mk(n, rows_o, 3, sc=0.5), mk(n_mol, rows_s, 3)
+    ws = [mk(ch, cin, sc=cin ** -0.5), mk(ch, cin, sc=cin ** -0.5), 1 + mk(ch, sc=0.2), mk(ch, sc=0.3)]
+    rm0, rv0 = mk(ch, sc=0.1) + 1.0, torch.rand(ch, generator=g).to(DEV) + 0.5
+    gout = mk(n, 3)
+    a = [t.clone().requires_grad_(True) for t in [x, o3] + ws]
+    rm, rv = rm0.clone(), rv0.clone()
+    out = HipVN.apply(a[0], a[1], shape, batch, a[2], a[3], a[4], a[5], rm, rv, training)
+    out.backward(gout)
+    b = [t.double().clone().requires_grad_(True) for t in [x, o3] + ws]
+    z = torch.cat((b[0].unsqueeze(1), b[1], shape.double()[batch]), dim=1)
+    pf = torch.einsum("oc,ncd->nod", b[2], z)
+    nrm = torch.sqrt((pf * pf).sum(2)) + 1e-6
+    if training:
+        mean, var = nrm.mean(0), ((nrm - nrm.mean(0)) ** 2).mean(0)
+    else:
+        mean, var = rm0.double(), rv0.double()
+    nbn = (nrm - mean) / torch.sqrt(var + 1e-5) * b[4] + b[5]
+    pf = pf / nrm.unsqueeze(2) * nbn.unsqueeze(2)
+    d = torch.einsum("oc,ncd->nod", b[3], z)
+    dot = (pf * d).sum(2, keepdim=True)
+    mask = (dot >= 0).double()
+    ref = (0.2 * pf + 0.8 * (mask * pf + (1 - mask) * (pf - (dot / ((d * d).sum(2, keepdim=True) + 1e-6)) * d))).mean(dim=1)
+    ref.backward(gout.double())
+    rel = lambda p, q: float((p.double() - q).abs().max() / q.abs().max().clamp(min=1e-6))  # noqa: E731
+    assert rel(out, ref.detach()) < 1e-5
+    errs = {nm: rel(p.grad, q.grad) for nm, p, q in zip(("dx", "do3", "dWf", "dWd", "dbn_w", "dbn_b"), a, b)}
+    assert max(errs.values()) < 1e-4, errs
+    if training:
+        cnt = nrm.shape[0]
+        assert rel(rm, 0.9 * rm0.double() + 0.1 * mean.detach()) < 1e-6
+        assert rel(rv, 0.9 * rv0.double() + 0.1 * var.detach() * cnt / max(cnt - 1, 1)) < 1e-6
+    else:
+        assert torch.equal(rm, rm0) and torch.equal(rv, rv0)
+
+
 def test_training_step_gradients_golden():
     """get_diffusion_loss with autograd enabled (the training step, scripts/train_diffusion.py:135-147) on the device: loss and
     the gradients of all 390 differentiated parameter tensors against the reference's own loss.backward() (grad_b12.npz),
