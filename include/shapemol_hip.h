@@ -175,16 +175,18 @@ int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_sh
  * evaluation when scripts/train_diffusion.py:135-147 calls loss.backward().  fp32 arithmetic (fp32 MFMA products), device
  * pointers, row-major: x (rows,k_in), w1 (hidden,k_in), b1/gamma/beta (hidden), w2 (n_out,hidden), b2 (n_out), y (rows,n_out).
  * _forward also writes xhat (rows,hidden) = the normalised pre-activation, rstd (rows) and act (rows,hidden) = the ReLU output
- * (scratch of the call; only xhat and rstd need to be kept for _backward).
+ * (xhat and rstd must be kept for _backward; act may be kept and handed back, or dropped: _backward recomputes it from xhat when
+ * d_act is NULL).
  * _backward: dy (rows,n_out) -> dx (rows,k_in; may be NULL), dw1, db1, dgamma, dbeta, dw2, db2 (OVERWRITTEN, not
- * accumulated); d_work: shapemol_mlp_backward_workspace() floats.  Reductions over the rows are deterministic. */
+ * accumulated); d_work: shapemol_mlp_backward_workspace() floats.  Reductions over the rows are deterministic.  When dgamma,
+ * dbeta, db1 are consecutive thirds of one (3 hidden) array they are reduced into it in one launch. */
 size_t shapemol_mlp_backward_workspace(int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out);
 int shapemol_mlp_forward(const float *d_x, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out, const float *d_w1,
                          const float *d_b1, const float *d_gamma, const float *d_beta, const float *d_w2, const float *d_b2,
                          float *d_y, float *d_xhat, float *d_rstd, float *d_act, void *stream);
 int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out,
                           const float *d_w1, const float *d_gamma, const float *d_beta, const float *d_w2, const float *d_xhat,
-                          const float *d_rstd, float *d_dx, float *d_dw1, float *d_db1, float *d_dgamma, float *d_dbeta,
+                          const float *d_rstd, const float *d_act, float *d_dx, float *d_dw1, float *d_db1, float *d_dgamma, float *d_dbeta,
                           float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream);
 
 /* The same block on edge rows whose input is the reference's concatenation [r_e | h_i | h_j | s_i] for edge e = (centre i = dst[e],
@@ -203,7 +205,7 @@ int shapemol_edge_mlp_forward(const float *d_r, const float *d_h, const float *d
 int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *d_s, const int64_t *d_ptr_dst, const int64_t *d_perm_src,
                                const int64_t *d_ptr_src, const float *d_dy, int64_t n_edges, int64_t n_nodes, int32_t k_edge, int32_t k_node,
                                int32_t k_shape, int32_t hidden, int32_t n_out, const float *d_w1, const float *d_gamma, const float *d_beta,
-                               const float *d_w2, const float *d_xhat, const float *d_rstd, float *d_dr, float *d_dh, float *d_ds, float *d_dw1,
+                               const float *d_w2, const float *d_xhat, const float *d_rstd, const float *d_act, float *d_dr, float *d_dh, float *d_ds, float *d_dw1,
                                float *d_db1, float *d_dgamma, float *d_dbeta, float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream);
 
 /* The coordinate update's vector-neuron block on the training path: VNLinearLeakyReLU with VNBatchNorm

@@ -94,11 +94,11 @@ def load():
     lib.shapemol_mlp_backward_workspace.restype = C.c_size_t
     lib.shapemol_mlp_backward_workspace.argtypes = [i64, i32, i32, i32]
     lib.shapemol_mlp_forward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.shapemol_mlp_backward.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.shapemol_mlp_backward.argtypes = [vp, vp, i64, i32, i32, i32] + [vp] * 15 + [C.c_size_t, vp]
     lib.shapemol_edge_mlp_backward_workspace.restype = C.c_size_t
     lib.shapemol_edge_mlp_backward_workspace.argtypes = [i64, i64, i32, i32, i32, i32, i32]
     lib.shapemol_edge_mlp_forward.argtypes = [vp] * 5 + [i64, i64] + [i32] * 5 + [vp] * 13
-    lib.shapemol_edge_mlp_backward.argtypes = [vp] * 7 + [i64, i64] + [i32] * 5 + [vp] * 16 + [C.c_size_t, vp]
+    lib.shapemol_edge_mlp_backward.argtypes = [vp] * 7 + [i64, i64] + [i32] * 5 + [vp] * 17 + [C.c_size_t, vp]
     lib.shapemol_vn_backward_workspace.restype = C.c_size_t
     lib.shapemol_vn_backward_workspace.argtypes = [i64, i32, i32, i32]
     lib.shapemol_vn_forward.argtypes = [vp] * 4 + [i64, i32, i32, i32] + [vp] * 6 + [i32] + [vp] * 6

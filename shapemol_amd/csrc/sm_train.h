@@ -100,6 +100,92 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
         }
 }
 
+// The same product for operands that have a unit stride and 16-byte aligned rows (every product of the training path but the
+// ones with a one-column operand): each thread moves one float4 of A and one of B per K chunk instead of four scalars of each
+// with 64-bit index arithmetic per element.  AK: A is k-contiguous (sak == 1), else m-contiguous (sam == 1); BN: B is
+// n-contiguous (sbn == 1), else k-contiguous (sbk == 1).  LDS rows are padded to 20 / 80 floats: float4 stores stay aligned
+// and the MFMA operand reads (16 rows x 4 k, 4 k x 16 columns) touch 64 distinct banks.
+__device__ __forceinline__ f32x4 gemm_load4(const float *p, int nvalid) {
+    if (nvalid >= 4) return *reinterpret_cast<const f32x4 *>(p);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (nvalid > 0) v[0] = p[0];
+    if (nvalid > 1) v[1] = p[1];
+    if (nvalid > 2) v[2] = p[2];
+    return v;
+}
+
+template <bool AK, bool BN>
+__global__ void __launch_bounds__(256) gemm_f32_vec_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[64][20];
+    __shared__ __attribute__((aligned(16))) float Bs[kGemmKC][80];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k_begin = blockIdx.z * a.kchunk, k_end = min(a.K, k_begin + a.kchunk);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this thread's float4 of the A tile and of the B tile
+    const int a_m = AK ? tid >> 2 : (tid & 15) * 4, a_k = AK ? (tid & 3) * 4 : tid >> 4;
+    const int b_n = BN ? (tid & 15) * 4 : tid >> 2, b_k = BN ? tid >> 4 : (tid & 3) * 4;
+    const float *pa = a.A + (long long)(m0 + a_m) * a.sam + (long long)(k_begin + a_k) * a.sak;
+    const float *pb = a.B + (long long)(k_begin + b_k) * a.sbk + (long long)(n0 + b_n) * a.sbn;
+    const long long step_a = (long long)kGemmKC * a.sak, step_b = (long long)kGemmKC * a.sbk;
+    const int a_mvalid = a.M - (m0 + a_m), b_nvalid = a.N - (n0 + b_n);
+    f32x4 ra, rb;
+    auto fetch = [&](int k0) {
+        ra = AK ? gemm_load4(pa, a_mvalid > 0 ? k_end - (k0 + a_k) : 0) : gemm_load4(pa, k0 + a_k < k_end ? a_mvalid : 0);
+        rb = BN ? gemm_load4(pb, k0 + b_k < k_end ? b_nvalid : 0) : gemm_load4(pb, b_nvalid > 0 ? k_end - (k0 + b_k) : 0);
+        pa += step_a; pb += step_b;
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += kGemmKC) {
+        if (AK) *reinterpret_cast<f32x4 *>(&As[a_m][a_k]) = ra;
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[a_m + i][a_k] = ra[i];
+        }
+        if (BN) *reinterpret_cast<f32x4 *>(&Bs[b_k][b_n]) = rb;
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Bs[b_k + i][b_n] = rb[i];
+        }
+        __syncthreads();
+        if (k0 + kGemmKC < k_end) fetch(k0 + kGemmKC);
+#pragma unroll
+        for (int kk = 0; kk < kGemmKC / 4; ++kk) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[wm * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[kk * 4 + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float *C = a.C + (size_t)blockIdx.z * a.M * a.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+            const float b = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r;
+                if (row < a.M && col < a.N) {
+                    float *dst = C + (size_t)row * a.ldc + col;
+                    *dst = acc[i][j][r] + b + (a.accum ? *dst : 0.f);
+                }
+            }
+        }
+}
+
 // out[i] = sum_s part[s * n + i] in a fixed order (which makes the parameter gradients deterministic): a workgroup owns 32
 // outputs, its 8 thread groups add every 8th partial (float64: partials of sums that cancel -- a bias in front of a
 // LayerNorm), the first group adds the 8 group sums.  (One thread per output walking all partials was a chain of up to 256
@@ -159,15 +245,16 @@ __global__ void __launch_bounds__(256) relu_affine_kernel(const float *xhat, con
     act[i] = fmaxf(xhat[i] * gamma[c] + beta[c], 0.f);
 }
 
-// Backward of LayerNorm + ReLU: da [rows][H] -> dz in place; the workgroup's sums of dpre * xhat and dpre over its rows go to
-// part[wg][2 H] (dgamma | dbeta partials).  kLnRows rows per workgroup, one wave per row at a time.
+// Backward of LayerNorm + ReLU: da [rows][H] -> dz in place; the workgroup's sums over its rows of dpre * xhat, dpre and dz go to
+// part[wg][3 H] (dgamma | dbeta | db1 partials: the first Linear's bias gradient is the column sum of dz).  kLnRows rows per
+// workgroup, one wave per row at a time.
 constexpr int kLnRows = 64;
 __global__ void __launch_bounds__(256) ln_relu_bwd_kernel(float *da, const float *xhat, const float *rstd, const float *gamma, const float *beta,
                                                           long long rows, int H, float *part) {
-    extern __shared__ float ln_sums[];                         // [4 waves][2 H]
+    extern __shared__ float ln_sums[];                         // [4 waves][3 H]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *mine = ln_sums + wave * 2 * H;
-    for (int c = lane; c < 2 * H; c += 64) mine[c] = 0.f;
+    float *mine = ln_sums + wave * 3 * H;
+    for (int c = lane; c < 3 * H; c += 64) mine[c] = 0.f;
     const long long r0 = (long long)blockIdx.x * kLnRows;
     for (int rr = wave; rr < kLnRows; rr += 4) {
         const long long row = r0 + rr;
@@ -186,21 +273,37 @@ __global__ void __launch_bounds__(256) ln_relu_bwd_kernel(float *da, const float
         }
         for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
         const float m1 = s1 / H, m2 = s2 / H, rs = rstd[row];
-        for (int c = lane; c < H; c += 64) dr[c] = rs * (dr[c] - m1 - xr[c] * m2);
+        for (int c = lane; c < H; c += 64) {
+            const float dz = rs * (dr[c] - m1 - xr[c] * m2);
+            dr[c] = dz;
+            mine[2 * H + c] += dz;
+        }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * H; c += 256)
-        part[(size_t)blockIdx.x * 2 * H + c] = (ln_sums[c] + ln_sums[2 * H + c]) + (ln_sums[4 * H + c] + ln_sums[6 * H + c]);
+    for (int c = threadIdx.x; c < 3 * H; c += 256)
+        part[(size_t)blockIdx.x * 3 * H + c] = (ln_sums[c] + ln_sums[3 * H + c]) + (ln_sums[6 * H + c] + ln_sums[9 * H + c]);
 }
 
-// Column sums of x [rows][cols] over blocks of kLnRows rows: part[wg][cols] (bias gradients).
+// Column sums of x [rows][cols] over blocks of kLnRows rows: part[wg][cols] (bias gradients).  The 256 threads are
+// 256 / cols row groups x cols columns (float64 sums, combined through LDS in a fixed order).
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float *x, long long rows, int cols, float *part) {
+    __shared__ double grp[256];
     const long long r0 = (long long)blockIdx.x * kLnRows;
     const long long r1 = r0 + kLnRows < rows ? r0 + kLnRows : rows;
-    for (int c = threadIdx.x; c < cols; c += 256) {
+    for (int c0 = 0; c0 < cols; c0 += 256) {
+        const int here = min(256, cols - c0), groups = 256 / here;
+        const int c = threadIdx.x % here, g = threadIdx.x / here;
         double s = 0.0;
-        for (long long r = r0; r < r1; ++r) s += (double)x[r * cols + c];
-        part[(size_t)blockIdx.x * cols + c] = (float)s;
+        if (g < groups)
+            for (long long r = r0 + g; r < r1; r += groups) s += (double)x[r * cols + c0 + c];
+        grp[threadIdx.x] = s;
+        __syncthreads();
+        if (g == 0) {
+            double t = 0.0;
+            for (int k = 0; k < groups; ++k) t += grp[k * here + c];
+            part[(size_t)blockIdx.x * cols + c0 + c] = (float)t;
+        }
+        __syncthreads();
     }
 }
 
@@ -223,10 +326,13 @@ __global__ void __launch_bounds__(256) seg_rowsum_kernel(const float *x, const l
 // Segment attention of the training path (models/uni_transformer.py:71-81 for x2h, :141-151 for h2x): for centre atom i with
 // incoming edges e in [ptr[i], ptr[i+1]) (edges grouped by centre, as the graph builder emits them) and head h
 //     logit_e = <q_i[h], k_e[h]> / sqrt(dh);   alpha = softmax over the atom's edges;   out_i[h][:] = sum_e alpha_e vals_e[h][:]
-// forward and backward in one pass each, one thread per (atom, head) (an atom has <= 32 edges; the backward recomputes the
-// softmax instead of storing alpha):  dvals_e = alpha_e dout_i;  dalpha_e = <dout_i, vals_e>;
+// and its backward (the softmax is recomputed, not stored):  dvals_e = alpha_e dout_i;  dalpha_e = <dout_i, vals_e>;
 //     dlogit_e = alpha_e (dalpha_e - sum_e' alpha_e' dalpha_e');   dq_i = sum_e dlogit_e k_e / sqrt(dh);   dk_e = dlogit_e q_i / sqrt(dh).
-// q [N][heads dh], k [E][heads dh], vals [E][heads][W] (W = dh for x2h, 3 for h2x: value times relative position), W <= 8.
+// q [N][heads dh], k [E][heads dh], vals [E][heads][W] (W = dh for x2h, 3 for h2x: value times relative position), dh, W <= 8.
+// Eight lanes per (atom, head): lane `sub` owns component sub of the head's q / k slice and of its value row, dot products are
+// 8-lane butterfly sums -- consecutive lanes read consecutive floats, and there are 8 x as many threads as (atom, head) pairs
+// (one thread per pair walked its edges with four dependent passes at 1.4 waves per SIMD: 126 us per backward at 5.5 k atoms).
+// Forward: one online-softmax pass.  Backward: one online pass for max, denominator and s = sum alpha dalpha, one for the gradients.
 struct SegAttnArgs {
     const float *q, *k, *vals;
     const long long *ptr;          // [N + 1]
@@ -237,60 +343,50 @@ struct SegAttnArgs {
 };
 constexpr int kSegAttnMaxW = 8, kSegAttnMaxDh = 8;
 
+__device__ __forceinline__ float sum8(float v) {
+    v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+
 template <bool BWD>
 __global__ void __launch_bounds__(256) seg_attention_kernel(SegAttnArgs a) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= a.n_atoms * a.heads) return;
-    const int i = gid / a.heads, h = gid % a.heads, H = a.heads * a.dh;
-    const long long e0 = a.ptr[i], e1 = a.ptr[i + 1];
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long grp = gid >> 3;
+    const int sub = (int)(gid & 7);
+    // (a whole 8-lane group is in or out together; out-of-range groups keep shuffling with zeros so that no lane of a wave is missing)
+    const bool live = grp < (long long)a.n_atoms * a.heads;
+    const long long i = live ? grp / a.heads : 0;
+    const int h = live ? (int)(grp % a.heads) : 0, H = a.heads * a.dh;
+    const long long e0 = live ? a.ptr[i] : 0, e1 = live ? a.ptr[i + 1] : 0;
+    const bool kd = sub < a.dh, vw = sub < a.W;
     const float scale = 1.0f / sqrtf((float)a.dh);
-    float qv[kSegAttnMaxDh];
-    for (int d = 0; d < a.dh; ++d) qv[d] = a.q[(size_t)i * H + h * a.dh + d];
-    // pass 1: maximum of the logits;  pass 2: sum of exponentials (and the forward's weighted sum)
-    float mx = -INFINITY;
+    const float qv = (live && kd) ? a.q[(size_t)i * H + h * a.dh + sub] : 0.f;
+    const float dov = (BWD && live && vw) ? a.dout[((size_t)i * a.heads + h) * a.W + sub] : 0.f;
+    const float *kp = a.k + h * a.dh + sub, *vp = a.vals + (size_t)h * a.W + sub;
+    float mx = -INFINITY, den = 0.f, acc = 0.f;             // acc: the forward's weighted sum (component sub) / the backward's sum of ex * dalpha
     for (long long e = e0; e < e1; ++e) {
-        float l = 0.f;
-        for (int d = 0; d < a.dh; ++d) l += qv[d] * a.k[(size_t)e * H + h * a.dh + d];
-        mx = fmaxf(mx, l * scale);
-    }
-    float den = 0.f, acc[kSegAttnMaxW];
-    for (int w = 0; w < a.W; ++w) acc[w] = 0.f;
-    for (long long e = e0; e < e1; ++e) {
-        float l = 0.f;
-        for (int d = 0; d < a.dh; ++d) l += qv[d] * a.k[(size_t)e * H + h * a.dh + d];
-        const float ex = expf(l * scale - mx);
-        den += ex;
-        if (!BWD)
-            for (int w = 0; w < a.W; ++w) acc[w] += ex * a.vals[((size_t)e * a.heads + h) * a.W + w];
+        const float kx = kd ? kp[(size_t)e * H] : 0.f, vx = vw ? vp[(size_t)e * a.heads * a.W] : 0.f;
+        const float l = sum8(qv * kx) * scale;
+        const float term = BWD ? sum8(dov * vx) : vx;
+        const float mn = fmaxf(mx, l), c = expf(mx - mn), ex = expf(l - mn);     // first edge: exp(-inf) = 0
+        den = den * c + ex;
+        acc = acc * c + ex * term;
+        mx = mn;
     }
     if (!BWD) {
-        for (int w = 0; w < a.W; ++w) a.out[((size_t)i * a.heads + h) * a.W + w] = e1 > e0 ? acc[w] / den : 0.f;
+        if (live && vw) a.out[((size_t)i * a.heads + h) * a.W + sub] = e1 > e0 ? acc / den : 0.f;
         return;
     }
-    float dov[kSegAttnMaxW];
-    for (int w = 0; w < a.W; ++w) dov[w] = a.dout[((size_t)i * a.heads + h) * a.W + w];
-    // pass 3: s = sum_e alpha_e dalpha_e;  pass 4: the gradients
-    float s = 0.f;
+    const float s = e1 > e0 ? acc / den : 0.f;
+    float dqv = 0.f;
     for (long long e = e0; e < e1; ++e) {
-        float l = 0.f, da = 0.f;
-        for (int d = 0; d < a.dh; ++d) l += qv[d] * a.k[(size_t)e * H + h * a.dh + d];
-        for (int w = 0; w < a.W; ++w) da += dov[w] * a.vals[((size_t)e * a.heads + h) * a.W + w];
-        s += expf(l * scale - mx) / den * da;
+        const float kx = kd ? kp[(size_t)e * H] : 0.f, vx = vw ? vp[(size_t)e * a.heads * a.W] : 0.f;
+        const float l = sum8(qv * kx) * scale, da = sum8(dov * vx);
+        const float al = expf(l - mx) / den, dl = al * (da - s) * scale;
+        if (vw) a.dvals[((size_t)e * a.heads + h) * a.W + sub] = al * dov;
+        if (kd) { dqv += dl * kx; a.dk[(size_t)e * H + h * a.dh + sub] = dl * qv; }
     }
-    float dqv[kSegAttnMaxDh];
-    for (int d = 0; d < a.dh; ++d) dqv[d] = 0.f;
-    for (long long e = e0; e < e1; ++e) {
-        float l = 0.f, da = 0.f;
-        for (int d = 0; d < a.dh; ++d) l += qv[d] * a.k[(size_t)e * H + h * a.dh + d];
-        for (int w = 0; w < a.W; ++w) da += dov[w] * a.vals[((size_t)e * a.heads + h) * a.W + w];
-        const float al = expf(l * scale - mx) / den, dl = al * (da - s) * scale;
-        for (int w = 0; w < a.W; ++w) a.dvals[((size_t)e * a.heads + h) * a.W + w] = al * dov[w];
-        for (int d = 0; d < a.dh; ++d) {
-            dqv[d] += dl * a.k[(size_t)e * H + h * a.dh + d];
-            a.dk[(size_t)e * H + h * a.dh + d] = dl * qv[d];
-        }
-    }
-    for (int d = 0; d < a.dh; ++d) a.dq[(size_t)i * H + h * a.dh + d] = dqv[d];
+    if (live && kd) a.dq[(size_t)i * H + h * a.dh + sub] = dqv;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 #include "sm_train.h"
 
 #include <algorithm>
+#include <cstdint>
 #include <string>
 
 extern "C" void shapemol_set_error_(const char *msg);     // shapemol_hip.hip: stores the thread's last error
@@ -24,7 +25,16 @@ int gemm(hipStream_t s, const float *A, long long sam, long long sak, const floa
     splits = accum ? 1 : std::max(1, splits);
     g.kchunk = ((K + splits - 1) / splits + kGemmKC - 1) / kGemmKC * kGemmKC;
     const int nz = (K + g.kchunk - 1) / g.kchunk;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, nz), dim3(256), 0, s, g);
+    const dim3 grid((N + 63) / 64, (M + 63) / 64, nz);
+    // the float4 kernel needs a unit stride in each operand and 16-byte aligned rows
+    auto al = [](const float *p, long long other) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && other % 4 == 0; };
+    const int am = (sak == 1 && al(A, sam)) ? 1 : (sam == 1 && al(A, sak)) ? 0 : -1;
+    const int bm = (sbn == 1 && al(B, sbk)) ? 1 : (sbk == 1 && al(B, sbn)) ? 0 : -1;
+    if (am < 0 || bm < 0) hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, g);
+    else if (am == 1 && bm == 1) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (am == 1) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (bm == 1) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false>), grid, dim3(256), 0, s, g);
     TRCHK(hipGetLastError());
     return 0;
 }
@@ -43,6 +53,19 @@ int real_splits(int64_t rows) {
     const int64_t kchunk = ((rows + sp - 1) / sp + kGemmKC - 1) / kGemmKC * kGemmKC;
     return (int)((rows + kchunk - 1) / kchunk);
 }
+// LayerNorm + ReLU backward on da [rows][H] (-> dz in place) and the three parameter gradients that are row sums of it:
+// dgamma | dbeta | db1, reduced straight into the caller's arrays when they are one [3 H] array (one launch instead of four)
+int ln_backward(hipStream_t s, float *dz, const float *xhat, const float *rstd, const float *gamma, const float *beta, int64_t rows, int H, int nwg,
+                float *pln, float *gb, float *dgamma, float *dbeta, float *db1) {
+    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nwg), dim3(256), (size_t)4 * 3 * H * sizeof(float), s, dz, xhat, rstd, gamma, beta, (long long)rows, H, pln);
+    TRCHK(hipGetLastError());
+    if (dbeta == dgamma + H && db1 == dgamma + 2 * H) return reduce_parts(s, pln, nwg, 3 * H, dgamma);
+    if (reduce_parts(s, pln, nwg, 3 * H, gb)) return 1;
+    TRCHK(hipMemcpyAsync(dgamma, gb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TRCHK(hipMemcpyAsync(dbeta, gb + H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TRCHK(hipMemcpyAsync(db1, gb + 2 * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
 bool bad_dims(int64_t rows, int k_in, int hidden, int n_out) {
     return rows < 1 || rows > (1ll << 26) || k_in < 1 || k_in > 4096 || hidden < 1 || hidden > 1024 || n_out < 1 || n_out > 4096;
 }
@@ -55,8 +78,8 @@ size_t shapemol_mlp_backward_workspace(int64_t rows, int32_t k_in, int32_t hidde
     const size_t nwg = (size_t)((rows + kLnRows - 1) / kLnRows), sp = (size_t)real_splits(rows);
     return 2 * (size_t)rows * hidden                              // activation a (recomputed) | da -> dz
            + sp * ((size_t)hidden * k_in + (size_t)n_out * hidden)   // split partials of dW1, dW2
-           + nwg * (3 * (size_t)hidden + n_out)                   // partials of dgamma | dbeta, db1, db2
-           + 2 * (size_t)hidden + 64;                             // dgamma | dbeta before they are handed out
+           + nwg * (3 * (size_t)hidden + n_out)                   // partials of dgamma | dbeta | db1, db2
+           + 3 * (size_t)hidden + 64;                             // dgamma | dbeta | db1 before they are handed out
 }
 
 int shapemol_mlp_forward(const float *d_x, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out, const float *d_w1,
@@ -77,45 +100,35 @@ int shapemol_mlp_forward(const float *d_x, int64_t rows, int32_t k_in, int32_t h
 
 int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out,
                           const float *d_w1, const float *d_gamma, const float *d_beta, const float *d_w2, const float *d_xhat,
-                          const float *d_rstd, float *d_dx, float *d_dw1, float *d_db1, float *d_dgamma, float *d_dbeta,
+                          const float *d_rstd, const float *d_act, float *d_dx, float *d_dw1, float *d_db1, float *d_dgamma, float *d_dbeta,
                           float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream) {
     if (!d_x || !d_dy || !d_w1 || !d_gamma || !d_beta || !d_w2 || !d_xhat || !d_rstd || !d_dw1 || !d_db1 || !d_dgamma || !d_dbeta ||
         !d_dw2 || !d_db2 || !d_work)
-        return tr_fail("shapemol_mlp_backward: null argument (only d_dx may be NULL)");
+        return tr_fail("shapemol_mlp_backward: null argument (only d_dx and d_act may be NULL)");
     if (bad_dims(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_backward: dimensions out of range");
     if (work_floats < shapemol_mlp_backward_workspace(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_backward: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int R = (int)rows, H = hidden;
     const int nwg = (int)((rows + kLnRows - 1) / kLnRows), sp = row_splits(rows), spr = real_splits(rows);
     float *act = d_work, *dz = act + (size_t)rows * H, *pw1 = dz + (size_t)rows * H, *pw2 = pw1 + (size_t)spr * H * k_in,
-          *pln = pw2 + (size_t)spr * n_out * H, *pb1 = pln + (size_t)nwg * 2 * H, *pb2 = pb1 + (size_t)nwg * H,
-          *gb = pb2 + (size_t)nwg * n_out;
+          *pln = pw2 + (size_t)spr * n_out * H, *pb2 = pln + (size_t)nwg * 3 * H, *gb = pb2 + (size_t)nwg * n_out;
     // da = dy W2  (A = dy [R][O], B(k, n) = W2[k][n])
     if (gemm(s, d_dy, n_out, 1, d_w2, H, 1, nullptr, dz, H, R, H, n_out, 1)) return 1;
     // db2 partials (column sums of dy)
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nwg), dim3(256), 0, s, d_dy, (long long)rows, n_out, pb2);
     TRCHK(hipGetLastError());
     if (reduce_parts(s, pb2, nwg, n_out, d_db2)) return 1;
-    // the activation a = relu(xhat * gamma + beta), recomputed (one elementwise pass instead of a second saved [rows][H] array
-    // per MLP), for dW2 = dy^T a:  A(m, k) = dy[k][m], B(k, n) = a[k][n], reduction over the rows in splits
-    hipLaunchKernelGGL(relu_affine_kernel, dim3((unsigned)(((long long)rows * H + 255) / 256)), dim3(256), 0, s, d_xhat, d_gamma, d_beta, act, (long long)rows, H);
-    TRCHK(hipGetLastError());
-    if (gemm(s, d_dy, 1, n_out, act, H, 1, nullptr, pw2, H, n_out, H, R, sp)) return 1;
-    if (reduce_parts(s, pw2, spr, (long long)n_out * H, d_dw2)) return 1;
-    // LayerNorm + ReLU backward: da -> dz in place, dgamma | dbeta partials
-    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nwg), dim3(256), (size_t)4 * 2 * H * sizeof(float), s, dz, d_xhat, d_rstd, d_gamma, d_beta, (long long)rows, H, pln);
-    TRCHK(hipGetLastError());
-    if (d_dbeta == d_dgamma + H) {                       // the caller's dgamma | dbeta are one array: reduce straight into it
-        if (reduce_parts(s, pln, nwg, 2 * H, d_dgamma)) return 1;
-    } else {
-        if (reduce_parts(s, pln, nwg, 2 * H, gb)) return 1;
-        TRCHK(hipMemcpyAsync(d_dgamma, gb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-        TRCHK(hipMemcpyAsync(d_dbeta, gb + H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // the activation a = relu(xhat * gamma + beta): the forward's, when the caller kept it, else recomputed from xhat;
+    // dW2 = dy^T a:  A(m, k) = dy[k][m], B(k, n) = a[k][n], reduction over the rows in splits
+    if (!d_act) {
+        hipLaunchKernelGGL(relu_affine_kernel, dim3((unsigned)(((long long)rows * H + 255) / 256)), dim3(256), 0, s, d_xhat, d_gamma, d_beta, act, (long long)rows, H);
+        TRCHK(hipGetLastError());
+        d_act = act;
     }
-    // db1 = column sums of dz
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nwg), dim3(256), 0, s, dz, (long long)rows, H, pb1);
-    TRCHK(hipGetLastError());
-    if (reduce_parts(s, pb1, nwg, H, d_db1)) return 1;
+    if (gemm(s, d_dy, 1, n_out, d_act, H, 1, nullptr, pw2, H, n_out, H, R, sp)) return 1;
+    if (reduce_parts(s, pw2, spr, (long long)n_out * H, d_dw2)) return 1;
+    // LayerNorm + ReLU backward: da -> dz in place, dgamma | dbeta | db1 partials
+    if (ln_backward(s, dz, d_xhat, d_rstd, d_gamma, d_beta, rows, H, nwg, pln, gb, d_dgamma, d_dbeta, d_db1)) return 1;
     // dW1 = dz^T x:  A(m, k) = dz[k][m], B(k, n) = x[k][n]
     if (gemm(s, dz, 1, H, d_x, k_in, 1, nullptr, pw1, k_in, H, k_in, R, sp)) return 1;
     if (reduce_parts(s, pw1, spr, (long long)H * k_in, d_dw1)) return 1;
@@ -137,7 +150,7 @@ static bool bad_edge_dims(const EdgeDims &d) {
 struct EdgeWork { size_t act, dz, dpd, dps, part, pln, pb, gb, total; };
 static EdgeWork edge_work(const EdgeDims &d) {
     const size_t spE = (size_t)real_splits(d.E), spN = (size_t)real_splits(d.N), hid = (size_t)d.hidden;
-    const size_t nwgE = (size_t)((d.E + kLnRows - 1) / kLnRows), nwgN = (size_t)((d.N + kLnRows - 1) / kLnRows);
+    const size_t nwgE = (size_t)((d.E + kLnRows - 1) / kLnRows);
     EdgeWork w;
     size_t o = 0;
     w.act = o; o += (size_t)d.E * hid;
@@ -145,9 +158,9 @@ static EdgeWork edge_work(const EdgeDims &d) {
     w.dpd = o; o += (size_t)d.N * hid;
     w.dps = o; o += (size_t)d.N * hid;
     w.part = o; o += std::max({spE * d.n_out * hid, spE * hid * d.kr, spN * hid * (size_t)std::max(d.H, d.Si)});
-    w.pln = o; o += nwgE * 2 * hid;
-    w.pb = o; o += std::max(nwgE * d.n_out, nwgN * hid);
-    w.gb = o; o += 2 * hid + 64;
+    w.pln = o; o += nwgE * 3 * hid;
+    w.pb = o; o += nwgE * d.n_out;
+    w.gb = o; o += 3 * hid + 64;
     w.total = o;
     return w;
 }
@@ -183,7 +196,7 @@ int shapemol_edge_mlp_forward(const float *d_r, const float *d_h, const float *d
 int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *d_s, const int64_t *d_ptr_dst, const int64_t *d_perm_src,
                                const int64_t *d_ptr_src, const float *d_dy, int64_t n_edges, int64_t n_nodes, int32_t k_edge, int32_t k_node,
                                int32_t k_shape, int32_t hidden, int32_t n_out, const float *d_w1, const float *d_gamma, const float *d_beta,
-                               const float *d_w2, const float *d_xhat, const float *d_rstd, float *d_dr, float *d_dh, float *d_ds, float *d_dw1,
+                               const float *d_w2, const float *d_xhat, const float *d_rstd, const float *d_act, float *d_dr, float *d_dh, float *d_ds, float *d_dw1,
                                float *d_db1, float *d_dgamma, float *d_dbeta, float *d_dw2, float *d_db2, float *d_work, size_t work_floats, void *stream) {
     if (!d_r || !d_h || !d_ptr_dst || !d_perm_src || !d_ptr_src || !d_dy || !d_w1 || !d_gamma || !d_beta || !d_w2 || !d_xhat || !d_rstd || !d_dr || !d_dh ||
         !d_dw1 || !d_db1 || !d_dgamma || !d_dbeta || !d_dw2 || !d_db2 || !d_work || (k_shape > 0 && (!d_s || !d_ds)))
@@ -194,7 +207,7 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
     if (work_floats < w.total) return tr_fail("shapemol_edge_mlp_backward: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int N = (int)n_nodes, E = (int)n_edges, K1 = d.K1, Hd = hidden;
-    const int nwgE = (int)((n_edges + kLnRows - 1) / kLnRows), nwgN = (int)((n_nodes + kLnRows - 1) / kLnRows);
+    const int nwgE = (int)((n_edges + kLnRows - 1) / kLnRows);
     const int spE = row_splits(n_edges), sprE = real_splits(n_edges), spN = row_splits(n_nodes), sprN = real_splits(n_nodes);
     float *act = d_work + w.act, *dz = d_work + w.dz, *dpd = d_work + w.dpd, *dps = d_work + w.dps, *part = d_work + w.part, *pln = d_work + w.pln,
           *pb = d_work + w.pb, *gb = d_work + w.gb;
@@ -206,19 +219,14 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nwgE), dim3(256), 0, s, d_dy, (long long)n_edges, n_out, pb);
     TRCHK(hipGetLastError());
     if (reduce_parts(s, pb, nwgE, n_out, d_db2)) return 1;
-    hipLaunchKernelGGL(relu_affine_kernel, dim3((unsigned)(((long long)n_edges * Hd + 255) / 256)), dim3(256), 0, s, d_xhat, d_gamma, d_beta, act, (long long)n_edges, Hd);
-    TRCHK(hipGetLastError());
-    if (gemm(s, d_dy, 1, n_out, act, Hd, 1, nullptr, part, Hd, n_out, Hd, E, spE)) return 1;
-    if (reduce_parts(s, part, sprE, (long long)n_out * Hd, d_dw2)) return 1;
-    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nwgE), dim3(256), (size_t)4 * 2 * Hd * sizeof(float), s, dz, d_xhat, d_rstd, d_gamma, d_beta, (long long)n_edges, Hd, pln);
-    TRCHK(hipGetLastError());
-    if (d_dbeta == d_dgamma + Hd) {
-        if (reduce_parts(s, pln, nwgE, 2 * Hd, d_dgamma)) return 1;
-    } else {
-        if (reduce_parts(s, pln, nwgE, 2 * Hd, gb)) return 1;
-        TRCHK(hipMemcpyAsync(d_dgamma, gb, (size_t)Hd * sizeof(float), hipMemcpyDeviceToDevice, s));
-        TRCHK(hipMemcpyAsync(d_dbeta, gb + Hd, (size_t)Hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!d_act) {
+        hipLaunchKernelGGL(relu_affine_kernel, dim3((unsigned)(((long long)n_edges * Hd + 255) / 256)), dim3(256), 0, s, d_xhat, d_gamma, d_beta, act, (long long)n_edges, Hd);
+        TRCHK(hipGetLastError());
+        d_act = act;
     }
+    if (gemm(s, d_dy, 1, n_out, d_act, Hd, 1, nullptr, part, Hd, n_out, Hd, E, spE)) return 1;
+    if (reduce_parts(s, part, sprE, (long long)n_out * Hd, d_dw2)) return 1;
+    if (ln_backward(s, dz, d_xhat, d_rstd, d_gamma, d_beta, n_edges, Hd, nwgE, pln, gb, d_dgamma, d_dbeta, d_db1)) return 1;      // db1 = sum_e dz_e
     // the edge term: dWr = dz^T r (column block 0 of dW1), dr = dz Wr
     if (gemm(s, dz, 1, Hd, d_r, k_edge, 1, nullptr, part, k_edge, Hd, k_edge, E, spE)) return 1;
     if (reduce_parts(s, part, sprE, (long long)Hd * k_edge, d_dw1, k_edge, K1)) return 1;
@@ -227,9 +235,6 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
     hipLaunchKernelGGL(seg_rowsum_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, s, (const float *)dz, ptr_dst, (const long long *)nullptr, dpd, (long long)n_nodes, Hd);
     hipLaunchKernelGGL(seg_rowsum_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, s, (const float *)dz, ptr_src, perm_src, dps, (long long)n_nodes, Hd);
     TRCHK(hipGetLastError());
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nwgN), dim3(256), 0, s, dpd, (long long)n_nodes, Hd, pb);       // db1 = sum_e dz_e = sum_i dpd_i
-    TRCHK(hipGetLastError());
-    if (reduce_parts(s, pb, nwgN, Hd, d_db1)) return 1;
     if (gemm(s, dpd, 1, Hd, d_h, k_node, 1, nullptr, part, k_node, Hd, k_node, N, spN)) return 1;                 // dWd = dpd^T h
     if (reduce_parts(s, part, sprN, (long long)Hd * k_node, d_dw1 + k_edge, k_node, K1)) return 1;
     if (gemm(s, dps, 1, Hd, d_h, k_node, 1, nullptr, part, k_node, Hd, k_node, N, spN)) return 1;                 // dWs = dps^T h
@@ -310,7 +315,7 @@ int shapemol_seg_attention_forward(const float *d_q, const float *d_k, const flo
     if (!d_q || !d_k || !d_vals || !d_ptr || !d_out) return tr_fail("shapemol_seg_attention_forward: null argument");
     if (n_atoms < 1 || heads < 1 || dh < 1 || dh > kSegAttnMaxDh || width < 1 || width > kSegAttnMaxW) return tr_fail("shapemol_seg_attention_forward: dimensions out of range (dh, width <= 8)");
     SegAttnArgs a{d_q, d_k, d_vals, reinterpret_cast<const long long *>(d_ptr), d_out, nullptr, nullptr, nullptr, nullptr, (int)n_atoms, heads, dh, width};
-    hipLaunchKernelGGL(seg_attention_kernel<false>, dim3((unsigned)((n_atoms * heads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(seg_attention_kernel<false>, dim3((unsigned)((n_atoms * heads * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     TRCHK(hipGetLastError());
     return 0;
 }
@@ -321,7 +326,7 @@ int shapemol_seg_attention_backward(const float *d_q, const float *d_k, const fl
     if (!d_q || !d_k || !d_vals || !d_ptr || !d_dout || !d_dq || !d_dk || !d_dvals) return tr_fail("shapemol_seg_attention_backward: null argument");
     if (n_atoms < 1 || heads < 1 || dh < 1 || dh > kSegAttnMaxDh || width < 1 || width > kSegAttnMaxW) return tr_fail("shapemol_seg_attention_backward: dimensions out of range (dh, width <= 8)");
     SegAttnArgs a{d_q, d_k, d_vals, reinterpret_cast<const long long *>(d_ptr), nullptr, d_dout, d_dq, d_dk, d_dvals, (int)n_atoms, heads, dh, width};
-    hipLaunchKernelGGL(seg_attention_kernel<true>, dim3((unsigned)((n_atoms * heads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(seg_attention_kernel<true>, dim3((unsigned)((n_atoms * heads * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     TRCHK(hipGetLastError());
     return 0;
 }

@@ -65,26 +65,26 @@ class HipMLP(torch.autograd.Function):
                                                       _p(ws[4]), _p(ws[5]), _p(y), _p(xhat), _p(rstd), _p(act),
                                                       C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
             _lib.check(rc, "shapemol_mlp_forward")
-        ctx.save_for_backward(x, ws[0], ws[2], ws[3], ws[4], xhat, rstd)
+        ctx.save_for_backward(x, ws[0], ws[2], ws[3], ws[4], xhat, rstd, act)
         ctx.dims = (rows, k_in, hidden, n_out)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w1, gamma, beta, w2, xhat, rstd = ctx.saved_tensors
+        x, w1, gamma, beta, w2, xhat, rstd, act = ctx.saved_tensors
         rows, k_in, hidden, n_out = ctx.dims
         dev = x.device
         dy = dy.contiguous().float()
         z = lambda *s: (torch.empty if rows > 0 else torch.zeros)(s, dtype=torch.float32, device=dev)  # noqa: E731  (the kernels overwrite)
-        dx, dw1, db1, gb, dw2, db2 = z(rows, k_in), z(hidden, k_in), z(hidden), z(2 * hidden), z(n_out, hidden), z(n_out)
-        dg, dbe = gb[:hidden], gb[hidden:]               # one array: the library reduces dgamma | dbeta into it in one launch
+        dx, dw1, gb, dw2, db2 = z(rows, k_in), z(hidden, k_in), z(3 * hidden), z(n_out, hidden), z(n_out)
+        dg, dbe, db1 = gb[:hidden], gb[hidden:2 * hidden], gb[2 * hidden:]     # one array: the library reduces the three into it in one launch
         if rows > 0:
             lib = _lib.load()
             n_work = lib.shapemol_mlp_backward_workspace(rows, k_in, hidden, n_out)
             work = torch.empty((n_work,), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.shapemol_mlp_backward(_p(x), _p(dy), rows, k_in, hidden, n_out, _p(w1), _p(gamma), _p(beta), _p(w2), _p(xhat),
-                                               _p(rstd), _p(dx) if ctx.needs_input_grad[0] else None, _p(dw1), _p(db1), _p(dg), _p(dbe),
+                                               _p(rstd), _p(act), _p(dx) if ctx.needs_input_grad[0] else None, _p(dw1), _p(db1), _p(dg), _p(dbe),
                                                _p(dw2), _p(db2), _p(work), n_work, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             _lib.check(rc, "shapemol_mlp_backward")
         return (dx if ctx.needs_input_grad[0] else None), dw1, db1, dg, dbe, dw2, db2
@@ -126,27 +126,27 @@ class HipEdgeMLP(torch.autograd.Function):
                                                            *[_p(t) for t in ws], _p(y), _p(xhat), _p(rstd), _p(act), _p(pd), _p(ps),
                                                            C.c_void_p(torch.cuda.current_stream(r.device).cuda_stream))
             _lib.check(rc, "shapemol_edge_mlp_forward")
-        ctx.save_for_backward(r, h, s, ws[0], ws[2], ws[3], ws[4], xhat, rstd)
+        ctx.save_for_backward(r, h, s, ws[0], ws[2], ws[3], ws[4], xhat, rstd, act)
         ctx.graph, ctx.dims = graph, (E, n, kr, kn, ks, hidden, n_out)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        r, h, s, w1, gamma, beta, w2, xhat, rstd = ctx.saved_tensors
+        r, h, s, w1, gamma, beta, w2, xhat, rstd, act = ctx.saved_tensors
         E, n, kr, kn, ks, hidden, n_out = ctx.dims
         g, dev = ctx.graph, r.device
         dy = dy.contiguous().float()
         z = lambda *sh: (torch.empty if E > 0 else torch.zeros)(sh, dtype=torch.float32, device=dev)  # noqa: E731  (the kernels overwrite)
         dr, dh, ds = z(E, kr), z(n, kn), z(n, ks)
-        dw1, db1, gb, dw2, db2 = z(hidden, kr + 2 * kn + ks), z(hidden), z(2 * hidden), z(n_out, hidden), z(n_out)
-        dg, dbe = gb[:hidden], gb[hidden:]
+        dw1, gb, dw2, db2 = z(hidden, kr + 2 * kn + ks), z(3 * hidden), z(n_out, hidden), z(n_out)
+        dg, dbe, db1 = gb[:hidden], gb[hidden:2 * hidden], gb[2 * hidden:]
         if E > 0:
             lib = _lib.load()
             n_work = lib.shapemol_edge_mlp_backward_workspace(E, n, kr, kn, ks, hidden, n_out)
             work = torch.empty((n_work,), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.shapemol_edge_mlp_backward(_p(r), _p(h), _p(s), _p(g.ptr), _p(g.perm_src), _p(g.ptr_src), _p(dy), E, n, kr, kn, ks, hidden, n_out,
-                                                    _p(w1), _p(gamma), _p(beta), _p(w2), _p(xhat), _p(rstd), _p(dr), _p(dh), _p(ds), _p(dw1), _p(db1),
+                                                    _p(w1), _p(gamma), _p(beta), _p(w2), _p(xhat), _p(rstd), _p(act), _p(dr), _p(dh), _p(ds), _p(dw1), _p(db1),
                                                     _p(dg), _p(dbe), _p(dw2), _p(db2), _p(work), n_work, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             _lib.check(rc, "shapemol_edge_mlp_backward")
         return dr, dh, ds, None, dw1, db1, dg, dbe, dw2, db2
