@@ -1260,3 +1260,29 @@ def test_training_step_gradients_golden():
     r2 = m.get_diffusion_loss(T(f["pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV).view(B, -1),
                               time_step=T(f["t"], DEV), eval_mode=True, noise=(T(noise, DEV), T(u, DEV)))
     assert float(r2["loss"]) < float(r["loss"])
+
+
+def test_training_step_gradients_deterministic():
+    """Two evaluations of the training step on the same batch give bit-identical losses and gradients (every reduction of the
+    HIP nodes runs in a fixed order, no atomics) -- at a batch large enough for the split reductions."""
+    import shapemol_amd
+    from util import model_cfg
+    cfg = model_cfg()
+    m = shapemol_amd.ScorePosNet3D(cfg, 15)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(cfg, seed=7).items()}, strict=True)
+    m = m.to(DEV).train()
+    B = 96
+    bb = synth.synthetic_batch(B, seed=11)
+    n = len(bb["batch"])
+    noise, u = synth.hash_normal((n, 3), 502, 11), synth.hash_uniform((n, 15), 503, 11)
+    t = torch.arange(B, device=DEV) * 10 % 1000
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        r = m.get_diffusion_loss(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV).view(B, -1),
+                                 time_step=t, eval_mode=True, noise=(T(noise, DEV), T(u, DEV)))
+        r["loss"].backward()
+        runs.append((r["loss"].detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    diff = [k for k in runs[0][1] if not torch.equal(runs[0][1][k], runs[1][1][k])]
+    assert not diff, diff[:5]
