@@ -178,8 +178,7 @@ int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_sh
  * (xhat and rstd must be kept for _backward; act may be kept and handed back, or dropped: _backward recomputes it from xhat when
  * d_act is NULL).
  * _backward: dy (rows,n_out) -> dx (rows,k_in; may be NULL), dw1, db1, dgamma, dbeta, dw2, db2 (OVERWRITTEN, not
- * accumulated); d_work: shapemol_mlp_backward_workspace() floats.  Reductions over the rows are deterministic.  When dgamma,
- * dbeta, db1 are consecutive thirds of one (3 hidden) array they are reduced into it in one launch. */
+ * accumulated); d_work: shapemol_mlp_backward_workspace() floats.  Reductions over the rows are deterministic. */
 size_t shapemol_mlp_backward_workspace(int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out);
 int shapemol_mlp_forward(const float *d_x, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out, const float *d_w1,
                          const float *d_b1, const float *d_gamma, const float *d_beta, const float *d_w2, const float *d_b2,
@@ -214,7 +213,7 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
  * molecule index of every atom, wf / wd (channels, 1 + rows_o + rows_s), out (n_atoms, 3).  training != 0: batch statistics
  * (running estimates, when given, updated with momentum 0.1 as nn.BatchNorm1d does); 0: the running estimates.  pf, dir
  * (n_atoms, channels, 3) and stats (2, channels) are kept for the backward; nrm (n_atoms, channels) is scratch.  _backward: dx,
- * do3, dw = dWf | dWd (2, channels, 1 + rows_o + rows_s), dbn_w, dbn_b from gout (n_atoms, 3); no gradient for shape (it comes
+ * do3, dwf, dwd (channels, 1 + rows_o + rows_s each), dbn_w, dbn_b from gout (n_atoms, 3); no gradient for shape (it comes
  * from the frozen encoder). */
 size_t shapemol_vn_backward_workspace(int64_t n_atoms, int32_t rows_o, int32_t rows_s, int32_t channels);
 int shapemol_vn_forward(const float *d_x, const float *d_o3, const float *d_shape, const int64_t *d_batch, int64_t n_atoms, int32_t rows_o,
@@ -224,7 +223,7 @@ int shapemol_vn_forward(const float *d_x, const float *d_o3, const float *d_shap
 int shapemol_vn_backward(const float *d_x, const float *d_o3, const float *d_shape, const int64_t *d_batch, int64_t n_atoms, int32_t rows_o,
                          int32_t rows_s, int32_t channels, const float *d_wf, const float *d_wd, const float *d_bn_w, const float *d_bn_b,
                          const float *d_pf, const float *d_dir, const float *d_stats, int32_t training, const float *d_gout, float *d_dx,
-                         float *d_do3, float *d_dw, float *d_dbn_w, float *d_dbn_b, float *d_work, size_t work_floats, void *stream);
+                         float *d_do3, float *d_dwf, float *d_dwd, float *d_dbn_w, float *d_dbn_b, float *d_work, size_t work_floats, void *stream);
 
 /* The attention of one layer on the training path (models/uni_transformer.py:71-81 / :141-151): for every centre atom i, whose
  * incoming edges are e in [ptr[i], ptr[i+1]) (edges grouped by centre), and head h: logits <q_i[h], k_e[h]> / sqrt(dh), softmax

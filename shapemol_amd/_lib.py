@@ -102,7 +102,7 @@ def load():
     lib.shapemol_vn_backward_workspace.restype = C.c_size_t
     lib.shapemol_vn_backward_workspace.argtypes = [i64, i32, i32, i32]
     lib.shapemol_vn_forward.argtypes = [vp] * 4 + [i64, i32, i32, i32] + [vp] * 6 + [i32] + [vp] * 6
-    lib.shapemol_vn_backward.argtypes = [vp] * 4 + [i64, i32, i32, i32] + [vp] * 7 + [i32] + [vp] * 7 + [C.c_size_t, vp]
+    lib.shapemol_vn_backward.argtypes = [vp] * 4 + [i64, i32, i32, i32] + [vp] * 7 + [i32] + [vp] * 8 + [C.c_size_t, vp]
     lib.shapemol_seg_attention_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]
     lib.shapemol_seg_attention_backward.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp]
     lib.shapemol_se_weight_count.restype = C.c_size_t

@@ -190,8 +190,10 @@ __global__ void __launch_bounds__(256) gemm_f32_vec_kernel(GemmArgs a) {
 // outputs, its 8 thread groups add every 8th partial (float64: partials of sums that cancel -- a bias in front of a
 // LayerNorm), the first group adds the 8 group sums.  (One thread per output walking all partials was a chain of up to 256
 // dependent loads: 27 % of a training step.)
-// The n outputs are a [n / cols][cols] matrix stored with row stride ldo (a column block of a wider gradient matrix).
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const float *part, int n_parts, long long n, float *out, int cols, int ldo) {
+// The n outputs are a [n / cols][cols] matrix stored with row stride ldo (a column block of a wider gradient matrix), or -- seg > 0
+// -- up to three separate arrays of seg outputs each (dgamma, dbeta, db1 of one MLP: one launch, three caller-owned tensors).
+struct ReduceOut { float *p[3]; long long seg; int cols, ldo; };
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float *part, int n_parts, long long n, ReduceOut o) {
     __shared__ double grp[8][32];
     const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
     const long long i = (long long)blockIdx.x * 32 + col;
@@ -204,7 +206,10 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float *part,
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += grp[k][col];
-        out[(i / cols) * ldo + i % cols] = (float)t;
+        if (o.seg > 0) {
+            const int which = (int)(i / o.seg);
+            (which == 0 ? o.p[0] : which == 1 ? o.p[1] : o.p[2])[i - which * o.seg] = (float)t;
+        } else o.p[0][(i / o.cols) * o.ldo + i % o.cols] = (float)t;
     }
 }
 

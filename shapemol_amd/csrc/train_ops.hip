@@ -40,7 +40,14 @@ int gemm(hipStream_t s, const float *A, long long sam, long long sak, const floa
 }
 int reduce_parts(hipStream_t s, const float *part, int n_parts, long long n, float *out, int cols = 0, int ldo = 0) {
     if (cols < 1) { cols = (int)std::min<long long>(n, 1 << 30); ldo = cols; }      // a plain vector
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, n_parts, n, out, cols, ldo);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, n_parts, n, ReduceOut{{out, nullptr, nullptr}, 0, cols, ldo});
+    TRCHK(hipGetLastError());
+    return 0;
+}
+// the same into up to three separate arrays of seg outputs each
+int reduce_parts3(hipStream_t s, const float *part, int n_parts, long long seg, float *o0, float *o1, float *o2) {
+    const long long n = seg * (o2 ? 3 : o1 ? 2 : 1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, n_parts, n, ReduceOut{{o0, o1, o2}, seg, 0, 0});
     TRCHK(hipGetLastError());
     return 0;
 }
@@ -54,17 +61,12 @@ int real_splits(int64_t rows) {
     return (int)((rows + kchunk - 1) / kchunk);
 }
 // LayerNorm + ReLU backward on da [rows][H] (-> dz in place) and the three parameter gradients that are row sums of it:
-// dgamma | dbeta | db1, reduced straight into the caller's arrays when they are one [3 H] array (one launch instead of four)
+// dgamma | dbeta | db1, reduced into the caller's three arrays by one launch
 int ln_backward(hipStream_t s, float *dz, const float *xhat, const float *rstd, const float *gamma, const float *beta, int64_t rows, int H, int nwg,
-                float *pln, float *gb, float *dgamma, float *dbeta, float *db1) {
+                float *pln, float *dgamma, float *dbeta, float *db1) {
     hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nwg), dim3(256), (size_t)4 * 3 * H * sizeof(float), s, dz, xhat, rstd, gamma, beta, (long long)rows, H, pln);
     TRCHK(hipGetLastError());
-    if (dbeta == dgamma + H && db1 == dgamma + 2 * H) return reduce_parts(s, pln, nwg, 3 * H, dgamma);
-    if (reduce_parts(s, pln, nwg, 3 * H, gb)) return 1;
-    TRCHK(hipMemcpyAsync(dgamma, gb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    TRCHK(hipMemcpyAsync(dbeta, gb + H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    TRCHK(hipMemcpyAsync(db1, gb + 2 * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return 0;
+    return reduce_parts3(s, pln, nwg, H, dgamma, dbeta, db1);
 }
 bool bad_dims(int64_t rows, int k_in, int hidden, int n_out) {
     return rows < 1 || rows > (1ll << 26) || k_in < 1 || k_in > 4096 || hidden < 1 || hidden > 1024 || n_out < 1 || n_out > 4096;
@@ -79,7 +81,7 @@ size_t shapemol_mlp_backward_workspace(int64_t rows, int32_t k_in, int32_t hidde
     return 2 * (size_t)rows * hidden                              // activation a (recomputed) | da -> dz
            + sp * ((size_t)hidden * k_in + (size_t)n_out * hidden)   // split partials of dW1, dW2
            + nwg * (3 * (size_t)hidden + n_out)                   // partials of dgamma | dbeta | db1, db2
-           + 3 * (size_t)hidden + 64;                             // dgamma | dbeta | db1 before they are handed out
+           + 64;
 }
 
 int shapemol_mlp_forward(const float *d_x, int64_t rows, int32_t k_in, int32_t hidden, int32_t n_out, const float *d_w1,
@@ -111,7 +113,7 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
     const int R = (int)rows, H = hidden;
     const int nwg = (int)((rows + kLnRows - 1) / kLnRows), sp = row_splits(rows), spr = real_splits(rows);
     float *act = d_work, *dz = act + (size_t)rows * H, *pw1 = dz + (size_t)rows * H, *pw2 = pw1 + (size_t)spr * H * k_in,
-          *pln = pw2 + (size_t)spr * n_out * H, *pb2 = pln + (size_t)nwg * 3 * H, *gb = pb2 + (size_t)nwg * n_out;
+          *pln = pw2 + (size_t)spr * n_out * H, *pb2 = pln + (size_t)nwg * 3 * H;
     // da = dy W2  (A = dy [R][O], B(k, n) = W2[k][n])
     if (gemm(s, d_dy, n_out, 1, d_w2, H, 1, nullptr, dz, H, R, H, n_out, 1)) return 1;
     // db2 partials (column sums of dy)
@@ -128,7 +130,7 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
     if (gemm(s, d_dy, 1, n_out, d_act, H, 1, nullptr, pw2, H, n_out, H, R, sp)) return 1;
     if (reduce_parts(s, pw2, spr, (long long)n_out * H, d_dw2)) return 1;
     // LayerNorm + ReLU backward: da -> dz in place, dgamma | dbeta | db1 partials
-    if (ln_backward(s, dz, d_xhat, d_rstd, d_gamma, d_beta, rows, H, nwg, pln, gb, d_dgamma, d_dbeta, d_db1)) return 1;
+    if (ln_backward(s, dz, d_xhat, d_rstd, d_gamma, d_beta, rows, H, nwg, pln, d_dgamma, d_dbeta, d_db1)) return 1;
     // dW1 = dz^T x:  A(m, k) = dz[k][m], B(k, n) = x[k][n]
     if (gemm(s, dz, 1, H, d_x, k_in, 1, nullptr, pw1, k_in, H, k_in, R, sp)) return 1;
     if (reduce_parts(s, pw1, spr, (long long)H * k_in, d_dw1)) return 1;
@@ -160,7 +162,7 @@ static EdgeWork edge_work(const EdgeDims &d) {
     w.part = o; o += std::max({spE * d.n_out * hid, spE * hid * d.kr, spN * hid * (size_t)std::max(d.H, d.Si)});
     w.pln = o; o += nwgE * 3 * hid;
     w.pb = o; o += nwgE * d.n_out;
-    w.gb = o; o += 3 * hid + 64;
+    w.gb = o; o += 64;
     w.total = o;
     return w;
 }
@@ -210,7 +212,7 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
     const int nwgE = (int)((n_edges + kLnRows - 1) / kLnRows);
     const int spE = row_splits(n_edges), sprE = real_splits(n_edges), spN = row_splits(n_nodes), sprN = real_splits(n_nodes);
     float *act = d_work + w.act, *dz = d_work + w.dz, *dpd = d_work + w.dpd, *dps = d_work + w.dps, *part = d_work + w.part, *pln = d_work + w.pln,
-          *pb = d_work + w.pb, *gb = d_work + w.gb;
+          *pb = d_work + w.pb;
     const float *wr = d_w1, *wd = d_w1 + k_edge, *ws = wd + k_node, *wi = ws + k_node;
     const long long *ptr_dst = reinterpret_cast<const long long *>(d_ptr_dst), *perm_src = reinterpret_cast<const long long *>(d_perm_src),
                     *ptr_src = reinterpret_cast<const long long *>(d_ptr_src);
@@ -226,7 +228,7 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
     }
     if (gemm(s, d_dy, 1, n_out, d_act, Hd, 1, nullptr, part, Hd, n_out, Hd, E, spE)) return 1;
     if (reduce_parts(s, part, sprE, (long long)n_out * Hd, d_dw2)) return 1;
-    if (ln_backward(s, dz, d_xhat, d_rstd, d_gamma, d_beta, n_edges, Hd, nwgE, pln, gb, d_dgamma, d_dbeta, d_db1)) return 1;      // db1 = sum_e dz_e
+    if (ln_backward(s, dz, d_xhat, d_rstd, d_gamma, d_beta, n_edges, Hd, nwgE, pln, d_dgamma, d_dbeta, d_db1)) return 1;      // db1 = sum_e dz_e
     // the edge term: dWr = dz^T r (column block 0 of dW1), dr = dz Wr
     if (gemm(s, dz, 1, Hd, d_r, k_edge, 1, nullptr, part, k_edge, Hd, k_edge, E, spE)) return 1;
     if (reduce_parts(s, part, sprE, (long long)Hd * k_edge, d_dw1, k_edge, K1)) return 1;
@@ -285,8 +287,8 @@ int shapemol_vn_forward(const float *d_x, const float *d_o3, const float *d_shap
 int shapemol_vn_backward(const float *d_x, const float *d_o3, const float *d_shape, const int64_t *d_batch, int64_t n_atoms, int32_t rows_o,
                          int32_t rows_s, int32_t channels, const float *d_wf, const float *d_wd, const float *d_bn_w, const float *d_bn_b,
                          const float *d_pf, const float *d_dir, const float *d_stats, int32_t training, const float *d_gout, float *d_dx,
-                         float *d_do3, float *d_dw, float *d_dbn_w, float *d_dbn_b, float *d_work, size_t work_floats, void *stream) {
-    if (!d_x || !d_batch || !d_wf || !d_wd || !d_bn_w || !d_bn_b || !d_pf || !d_dir || !d_stats || !d_gout || !d_dx || !d_dw || !d_dbn_w || !d_dbn_b ||
+                         float *d_do3, float *d_dwf, float *d_dwd, float *d_dbn_w, float *d_dbn_b, float *d_work, size_t work_floats, void *stream) {
+    if (!d_x || !d_batch || !d_wf || !d_wd || !d_bn_w || !d_bn_b || !d_pf || !d_dir || !d_stats || !d_gout || !d_dx || !d_dwf || !d_dwd || !d_dbn_w || !d_dbn_b ||
         !d_work || (rows_o > 0 && (!d_o3 || !d_do3)) || (rows_s > 0 && !d_shape))
         return tr_fail("shapemol_vn_backward: null argument");
     if (bad_vn_dims(n_atoms, rows_o, rows_s, channels)) return tr_fail("shapemol_vn_backward: dimensions out of range (channels <= 64)");
@@ -307,7 +309,7 @@ int shapemol_vn_backward(const float *d_x, const float *d_o3, const float *d_sha
     hipLaunchKernelGGL(vn_bwd_stats_kernel, dim3(channels), dim3(256), 0, s, a);
     hipLaunchKernelGGL(vn_bwd_b_kernel, dim3(nwg), dim3(256), ((size_t)2 * channels * Cin + (size_t)2 * per * channels * 3) * sizeof(float), s, a);
     TRCHK(hipGetLastError());
-    return reduce_parts(s, a.wpart, (int)nwg, (long long)2 * channels * Cin, d_dw);        // dWf | dWd
+    return reduce_parts3(s, a.wpart, (int)nwg, (long long)channels * Cin, d_dwf, d_dwd, nullptr);
 }
 
 int shapemol_seg_attention_forward(const float *d_q, const float *d_k, const float *d_vals, const int64_t *d_ptr, int64_t n_atoms,

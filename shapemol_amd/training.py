@@ -76,8 +76,7 @@ class HipMLP(torch.autograd.Function):
         dev = x.device
         dy = dy.contiguous().float()
         z = lambda *s: (torch.empty if rows > 0 else torch.zeros)(s, dtype=torch.float32, device=dev)  # noqa: E731  (the kernels overwrite)
-        dx, dw1, gb, dw2, db2 = z(rows, k_in), z(hidden, k_in), z(3 * hidden), z(n_out, hidden), z(n_out)
-        dg, dbe, db1 = gb[:hidden], gb[hidden:2 * hidden], gb[2 * hidden:]     # one array: the library reduces the three into it in one launch
+        dx, dw1, db1, dg, dbe, dw2, db2 = z(rows, k_in), z(hidden, k_in), z(hidden), z(hidden), z(hidden), z(n_out, hidden), z(n_out)
         if rows > 0:
             lib = _lib.load()
             n_work = lib.shapemol_mlp_backward_workspace(rows, k_in, hidden, n_out)
@@ -138,8 +137,7 @@ class HipEdgeMLP(torch.autograd.Function):
         dy = dy.contiguous().float()
         z = lambda *sh: (torch.empty if E > 0 else torch.zeros)(sh, dtype=torch.float32, device=dev)  # noqa: E731  (the kernels overwrite)
         dr, dh, ds = z(E, kr), z(n, kn), z(n, ks)
-        dw1, gb, dw2, db2 = z(hidden, kr + 2 * kn + ks), z(3 * hidden), z(n_out, hidden), z(n_out)
-        dg, dbe, db1 = gb[:hidden], gb[hidden:2 * hidden], gb[2 * hidden:]
+        dw1, db1, dg, dbe, dw2, db2 = z(hidden, kr + 2 * kn + ks), z(hidden), z(hidden), z(hidden), z(n_out, hidden), z(n_out)
         if E > 0:
             lib = _lib.load()
             n_work = lib.shapemol_edge_mlp_backward_workspace(E, n, kr, kn, ks, hidden, n_out)
@@ -227,16 +225,16 @@ class HipVN(torch.autograd.Function):
         dev = x.device
         gout = gout.contiguous().float()
         new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
-        dx, do3, dw, dg, db = new(n, 3), new(n, rows_o, 3), new(2, ch, 1 + rows_o + rows_s), new(ch), new(ch)
+        dx, do3, dwf, dwd, dg, db = new(n, 3), new(n, rows_o, 3), new(ch, 1 + rows_o + rows_s), new(ch, 1 + rows_o + rows_s), new(ch), new(ch)
         lib = _lib.load()
         n_work = lib.shapemol_vn_backward_workspace(n, rows_o, rows_s, ch)
         work = new(n_work)
         with torch.cuda.device(dev):
             rc = lib.shapemol_vn_backward(_p(x), _p(o3), _p(shape), _p(batch), n, rows_o, rows_s, ch, _p(wf), _p(wd), _p(bn_w), _p(bn_b), _p(pf), _p(dr),
-                                          _p(stats), training, _p(gout), _p(dx), _p(do3), _p(dw), _p(dg), _p(db), _p(work), n_work,
+                                          _p(stats), training, _p(gout), _p(dx), _p(do3), _p(dwf), _p(dwd), _p(dg), _p(db), _p(work), n_work,
                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         _lib.check(rc, "shapemol_vn_backward")
-        return dx, do3, None, None, dw[0], dw[1], dg, db, None, None, None
+        return dx, do3, None, None, dwf, dwd, dg, db, None, None, None
 
 
 def _mlp(P, prefix, x):
