@@ -193,19 +193,23 @@ __global__ void __launch_bounds__(256) gemm_f32_vec_kernel(GemmArgs a) {
 // The n outputs are a [n / cols][cols] matrix stored with row stride ldo (a column block of a wider gradient matrix), or -- seg > 0
 // -- up to three separate arrays of seg outputs each (dgamma, dbeta, db1 of one MLP: one launch, three caller-owned tensors).
 struct ReduceOut { float *p[3]; long long seg; int cols, ldo; };
+// GROUPS thread groups of 256 / GROUPS outputs each: 8 x 32 for a few partials, 32 x 8 for many (the per-thread chain of dependent
+// loads is n_parts / GROUPS long, and with 173 partials of a small matrix that chain, not the bytes, is the kernel's time)
+template <int GROUPS>
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float *part, int n_parts, long long n, ReduceOut o) {
-    __shared__ double grp[8][32];
-    const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const long long i = (long long)blockIdx.x * 32 + col;
+    constexpr int COLS = 256 / GROUPS;
+    __shared__ double grp[GROUPS][COLS];
+    const int col = threadIdx.x % COLS, g = threadIdx.x / COLS;
+    const long long i = (long long)blockIdx.x * COLS + col;
     double s = 0.0;
     if (i < n)
-        for (int p = g; p < n_parts; p += 8) s += (double)part[(size_t)p * n + i];
+        for (int p = g; p < n_parts; p += GROUPS) s += (double)part[(size_t)p * n + i];
     grp[g][col] = s;
     __syncthreads();
     if (g == 0 && i < n) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += grp[k][col];
+        for (int k = 0; k < GROUPS; ++k) t += grp[k][col];
         if (o.seg > 0) {
             const int which = (int)(i / o.seg);
             (which == 0 ? o.p[0] : which == 1 ? o.p[1] : o.p[2])[i - which * o.seg] = (float)t;
@@ -253,15 +257,15 @@ __global__ void __launch_bounds__(256) relu_affine_kernel(const float *xhat, con
 // Backward of LayerNorm + ReLU: da [rows][H] -> dz in place; the workgroup's sums over its rows of dpre * xhat, dpre and dz go to
 // part[wg][3 H] (dgamma | dbeta | db1 partials: the first Linear's bias gradient is the column sum of dz).  kLnRows rows per
 // workgroup, one wave per row at a time.
-constexpr int kLnRows = 64;
-__global__ void __launch_bounds__(256) ln_relu_bwd_kernel(float *da, const float *xhat, const float *rstd, const float *gamma, const float *beta,
-                                                          long long rows, int H, float *part) {
-    extern __shared__ float ln_sums[];                         // [4 waves][3 H]
+constexpr int kLnRows = 64, kLnBwdWaves = 16;       // 16 waves: four rows each (with four waves a row's loads waited for the previous row's: 1.6 TB/s)
+__global__ void __launch_bounds__(kLnBwdWaves * 64) ln_relu_bwd_kernel(float *da, const float *xhat, const float *rstd, const float *gamma, const float *beta,
+                                                                        long long rows, int H, float *part) {
+    extern __shared__ float ln_sums[];                         // [waves][3 H]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *mine = ln_sums + wave * 3 * H;
     for (int c = lane; c < 3 * H; c += 64) mine[c] = 0.f;
     const long long r0 = (long long)blockIdx.x * kLnRows;
-    for (int rr = wave; rr < kLnRows; rr += 4) {
+    for (int rr = wave; rr < kLnRows; rr += kLnBwdWaves) {
         const long long row = r0 + rr;
         if (row >= rows) break;
         float *dr = da + row * H;
@@ -285,8 +289,11 @@ __global__ void __launch_bounds__(256) ln_relu_bwd_kernel(float *da, const float
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 3 * H; c += 256)
-        part[(size_t)blockIdx.x * 3 * H + c] = (ln_sums[c] + ln_sums[3 * H + c]) + (ln_sums[6 * H + c] + ln_sums[9 * H + c]);
+    for (int c = threadIdx.x; c < 3 * H; c += kLnBwdWaves * 64) {
+        float t = 0.f;
+        for (int w = 0; w < kLnBwdWaves; ++w) t += ln_sums[w * 3 * H + c];
+        part[(size_t)blockIdx.x * 3 * H + c] = t;
+    }
 }
 
 // Column sums of x [rows][cols] over blocks of kLnRows rows: part[wg][cols] (bias gradients).  The 256 threads are

@@ -10,6 +10,7 @@
 extern "C" void shapemol_set_error_(const char *msg);     // shapemol_hip.hip: stores the thread's last error
 
 namespace {
+constexpr int kMaxHidden = 256;      // ln_relu_bwd_kernel keeps 16 waves x 3 hidden floats in LDS (48 KB at 256)
 int tr_fail(const std::string &m) { shapemol_set_error_(m.c_str()); return 1; }
 #define TRCHK(expr)                                                                          \
     do {                                                                                     \
@@ -40,14 +41,16 @@ int gemm(hipStream_t s, const float *A, long long sam, long long sak, const floa
 }
 int reduce_parts(hipStream_t s, const float *part, int n_parts, long long n, float *out, int cols = 0, int ldo = 0) {
     if (cols < 1) { cols = (int)std::min<long long>(n, 1 << 30); ldo = cols; }      // a plain vector
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, n_parts, n, ReduceOut{{out, nullptr, nullptr}, 0, cols, ldo});
+    if (n_parts > 32) hipLaunchKernelGGL(reduce_partials_kernel<32>, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, s, part, n_parts, n, ReduceOut{{out, nullptr, nullptr}, 0, cols, ldo});
+    else hipLaunchKernelGGL(reduce_partials_kernel<8>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, n_parts, n, ReduceOut{{out, nullptr, nullptr}, 0, cols, ldo});
     TRCHK(hipGetLastError());
     return 0;
 }
 // the same into up to three separate arrays of seg outputs each
 int reduce_parts3(hipStream_t s, const float *part, int n_parts, long long seg, float *o0, float *o1, float *o2) {
     const long long n = seg * (o2 ? 3 : o1 ? 2 : 1);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, n_parts, n, ReduceOut{{o0, o1, o2}, seg, 0, 0});
+    if (n_parts > 32) hipLaunchKernelGGL(reduce_partials_kernel<32>, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, s, part, n_parts, n, ReduceOut{{o0, o1, o2}, seg, 0, 0});
+    else hipLaunchKernelGGL(reduce_partials_kernel<8>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, n_parts, n, ReduceOut{{o0, o1, o2}, seg, 0, 0});
     TRCHK(hipGetLastError());
     return 0;
 }
@@ -64,12 +67,12 @@ int real_splits(int64_t rows) {
 // dgamma | dbeta | db1, reduced into the caller's three arrays by one launch
 int ln_backward(hipStream_t s, float *dz, const float *xhat, const float *rstd, const float *gamma, const float *beta, int64_t rows, int H, int nwg,
                 float *pln, float *dgamma, float *dbeta, float *db1) {
-    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nwg), dim3(256), (size_t)4 * 3 * H * sizeof(float), s, dz, xhat, rstd, gamma, beta, (long long)rows, H, pln);
+    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nwg), dim3(kLnBwdWaves * 64), (size_t)kLnBwdWaves * 3 * H * sizeof(float), s, dz, xhat, rstd, gamma, beta, (long long)rows, H, pln);
     TRCHK(hipGetLastError());
     return reduce_parts3(s, pln, nwg, H, dgamma, dbeta, db1);
 }
 bool bad_dims(int64_t rows, int k_in, int hidden, int n_out) {
-    return rows < 1 || rows > (1ll << 26) || k_in < 1 || k_in > 4096 || hidden < 1 || hidden > 1024 || n_out < 1 || n_out > 4096;
+    return rows < 1 || rows > (1ll << 26) || k_in < 1 || k_in > 4096 || hidden < 1 || hidden > kMaxHidden || n_out < 1 || n_out > 4096;
 }
 }  // namespace
 
@@ -89,7 +92,7 @@ int shapemol_mlp_forward(const float *d_x, int64_t rows, int32_t k_in, int32_t h
                          float *d_y, float *d_xhat, float *d_rstd, float *d_act, void *stream) {
     if (!d_x || !d_w1 || !d_b1 || !d_gamma || !d_beta || !d_w2 || !d_b2 || !d_y || !d_xhat || !d_rstd || !d_act)
         return tr_fail("shapemol_mlp_forward: null argument");
-    if (bad_dims(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_forward: dimensions out of range");
+    if (bad_dims(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_forward: dimensions out of range (hidden <= 256)");
     hipStream_t s = (hipStream_t)stream;
     // z = x W1^T + b1  (B(k, n) = W1[n][k])
     if (gemm(s, d_x, k_in, 1, d_w1, 1, k_in, d_b1, d_act, hidden, (int)rows, hidden, k_in, 1)) return 1;
@@ -107,7 +110,7 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
     if (!d_x || !d_dy || !d_w1 || !d_gamma || !d_beta || !d_w2 || !d_xhat || !d_rstd || !d_dw1 || !d_db1 || !d_dgamma || !d_dbeta ||
         !d_dw2 || !d_db2 || !d_work)
         return tr_fail("shapemol_mlp_backward: null argument (only d_dx and d_act may be NULL)");
-    if (bad_dims(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_backward: dimensions out of range");
+    if (bad_dims(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_backward: dimensions out of range (hidden <= 256)");
     if (work_floats < shapemol_mlp_backward_workspace(rows, k_in, hidden, n_out)) return tr_fail("shapemol_mlp_backward: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int R = (int)rows, H = hidden;
@@ -147,7 +150,7 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
 struct EdgeDims { int64_t E, N; int kr, H, Si, hidden, n_out, K1; };
 static bool bad_edge_dims(const EdgeDims &d) {
     return d.E < 1 || d.E > (1ll << 26) || d.N < 1 || d.N > (1ll << 26) || d.kr < 1 || d.kr > 1024 || d.H < 1 || d.H > 1024 || d.Si < 0 || d.Si > 1024 ||
-           d.hidden < 1 || d.hidden > 1024 || d.n_out < 1 || d.n_out > 4096;
+           d.hidden < 1 || d.hidden > kMaxHidden || d.n_out < 1 || d.n_out > 4096;
 }
 struct EdgeWork { size_t act, dz, dpd, dps, part, pln, pb, gb, total; };
 static EdgeWork edge_work(const EdgeDims &d) {
