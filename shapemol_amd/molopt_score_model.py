@@ -378,8 +378,8 @@ class ScorePosNet3D(nn.Module):
             assert guide_stren == 0
         if guide_stren:
             raise NotImplementedError("classifier-free guidance is unreachable in the reference (SURVEY.md F10)")
-        if center_pos_mode not in (None, "none"):
-            raise NotImplementedError("center_pos_mode != 'none'")
+        if center_pos_mode not in (None, "none", "center"):
+            raise NotImplementedError(center_pos_mode)       # as center_pos() of the reference (:52-60)
         if num_steps is None:
             num_steps = self.num_timesteps
         print('sample center pos mode: ', center_pos_mode)
@@ -389,6 +389,13 @@ class ScorePosNet3D(nn.Module):
         batch = _check_device_tensor("batch_ligand", batch_ligand, torch.int64)
         shape = _check_device_tensor("ligand_shape", ligand_shape, torch.float32).view(-1, self.dims.S, 3)
         n, b, cc, dev = pos.shape[0], shape.shape[0], self.dims.C, pos.device
+        offset = None
+        if center_pos_mode == "center":
+            # the chain runs on coordinates centred per molecule; the offset goes back onto `pos` and `pos_traj` (reference :547,
+            # :675-684; `pos_cond_traj`, the raw network outputs, stays in the centred frame there too)
+            cnt = torch.bincount(batch, minlength=b).clamp(min=1).to(torch.float32)
+            offset = (torch.zeros((b, 3), dtype=torch.float32, device=dev).index_add_(0, batch, pos) / cnt[:, None])[batch]
+            pos = pos - offset
         ctx = self._context(dev, _slot)
         self._sync_bn_mode(ctx, _slot)
         lib = _lib.load()
@@ -433,7 +440,7 @@ class ScorePosNet3D(nn.Module):
         out_pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
         out_v = torch.empty((n,), dtype=torch.int64, device=dev)
         pending = _PendingChain(self, ctx, dev, guided, bufs, out_pos, out_v, return_traj, _reuse_host_buffers,
-                                keep=(pos, v, batch, shape, eps, u, gd))
+                                keep=(pos, v, batch, shape, eps, u, gd), offset=offset)
         try:
             with torch.cuda.device(dev):
                 cur = torch.cuda.current_stream(dev)
@@ -496,7 +503,8 @@ class _PendingChain:
     """A reverse chain that has been enqueued on its context's side stream (ScorePosNet3D.sample_diffusion(_async=True));
     result() waits for it, reads the status flags and builds the reference's result dict."""
 
-    def __init__(self, model, ctx, dev, guided, bufs, out_pos, out_v, return_traj, reuse, keep):
+    def __init__(self, model, ctx, dev, guided, bufs, out_pos, out_v, return_traj, reuse, keep, offset=None):
+        self.offset = offset                 # (N, 3) per-atom centre of its molecule (center_pos_mode='center') or None
         self.model, self.ctx, self.dev, self.guided, self.bufs = model, ctx, dev, guided, bufs
         self.out_pos, self.out_v, self.return_traj, self.reuse, self.keep = out_pos, out_v, return_traj, reuse, keep
         self.side = self.cur = None
@@ -526,6 +534,10 @@ class _PendingChain:
         for t_ in (*self.keep, self.out_pos, self.out_v, *bufs.values()):
             if t_ is not None:
                 t_.record_stream(self.side)
+        if self.offset is not None:
+            self.out_pos += self.offset
+            if "pos_traj" in bufs:
+                bufs["pos_traj"] += self.offset.unsqueeze(0)
         res = {"pos": self.out_pos, "v": self.out_v, "pos_uncond_traj": [], "v_uncond_traj": []}
         if self.return_traj and self.reuse == "device":
             # private to shapemol_amd.sampling: hand out the (S, N, ...) device buffers; the driver reorders them on the

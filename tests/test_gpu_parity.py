@@ -1286,3 +1286,26 @@ def test_training_step_gradients_deterministic():
     assert torch.equal(runs[0][0], runs[1][0])
     diff = [k for k in runs[0][1] if not torch.equal(runs[0][1][k], runs[1][1][k])]
     assert not diff, diff[:5]
+
+
+def test_chain_center_pos_mode_center():
+    """center_pos_mode='center' (reference :52-60, :547, :675-684): the chain runs on per-molecule centred coordinates and the
+    offset returns onto `pos` and `pos_traj` only.  Checked against the 'none' chain of the pre-centred input on the same
+    draws (which the golden fixture pins to the reference): identical atom types, pos / pos_traj shifted by the offset,
+    pos_cond_traj unshifted."""
+    m = hip_model()
+    c = golden("chain_b4_s50_torchrng.npz")
+    batch = torch.from_numpy(c["batch"])
+    shift = torch.tensor([[3.0, -2.0, 1.0], [-5.0, 0.5, 2.5], [0.25, 4.0, -6.0], [1.5, 1.5, -0.75]])[batch]
+    pos0 = torch.from_numpy(c["init_pos"])
+    mean = torch.stack([pos0[batch == b].mean(0) for b in range(4)])[batch]
+    moved = (pos0 - mean + shift).numpy()                       # molecule b centred at shift[b]
+    base = _chain(m, (pos0 - mean).numpy(), c["init_v"], c["batch"], c["shape"], 20, c["eps"][:20], c["u"][:20])
+    res = m.sample_diffusion(T(moved, DEV), T(c["init_v"], DEV), T(c["batch"], DEV), T(c["shape"], DEV).view(4, -1), num_steps=20,
+                             center_pos_mode="center", noise=(T(c["eps"][:20], DEV), T(c["u"][:20], DEV)))
+    assert torch.equal(res["v"], base["v"]) and torch.equal(torch.stack(res["v_traj"]), torch.stack(base["v_traj"]))
+    assert maxabs(res["pos"].cpu() - shift, base["pos"].cpu().numpy()) < 2e-5
+    assert maxabs(torch.stack(res["pos_traj"]) - shift.unsqueeze(0), torch.stack(base["pos_traj"]).numpy()) < 2e-5
+    assert maxabs(torch.stack(res["pos_cond_traj"]).cpu(), torch.stack(base["pos_cond_traj"]).cpu().numpy()) < 2e-5
+    with pytest.raises(NotImplementedError):
+        m.sample_diffusion(T(moved, DEV), T(c["init_v"], DEV), T(c["batch"], DEV), T(c["shape"], DEV).view(4, -1), num_steps=2, center_pos_mode="mass")
