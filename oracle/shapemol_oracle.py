@@ -331,15 +331,23 @@ def _diffusion_loss(sd, dm, pos, v, batch, shape, t, pos_noise, u, bn_eval, loss
 
 
 @torch.no_grad()
-def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, keep_traj=True, guidance=None, bn_eval=False, first_step=0):
+def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, keep_traj=True, guidance=None, bn_eval=False, first_step=0,
+                 center=False):
     """Reverse chain t = T-1 ... T-num_steps with host-fed noise ``noise_fn(step) -> (eps, u)``
     (numpy or torch arrays; per step eps (N,3) first, then u (N,C), the reference's draw order).
     first_step = s0 resumes a chain at reverse step s0 (t = T-1-s0) from the given state; noise_fn still counts from 0.
     guidance = (cloud, radius, grad_step, draws (S,5,N)): point-cloud guidance of the predicted x0 while t > grad_step
-    (/root/reference/models/molopt_score_model.py:583-586)."""
+    (/root/reference/models/molopt_score_model.py:583-586).
+    center: center_pos_mode='center' (:52-60, :547, :675-684): the chain runs on coordinates centred per molecule, the offset
+    returns onto pos and pos_traj."""
     B = int(batch.max()) + 1
     shape = shape.view(B, -1, 3)
     pos, v = init_pos, init_v
+    offset = 0.0
+    if center:
+        cnt = torch.bincount(batch, minlength=B).to(pos.dtype).clamp(min=1)
+        offset = (torch.zeros((B, 3), dtype=pos.dtype).index_add_(0, batch, pos) / cnt[:, None])[batch]
+        pos = pos - offset
     out = {k: [] for k in ("pos_traj", "v_traj", "v0_traj", "vt_traj", "pos_cond_traj", "v_cond_traj")}
     for s, i in enumerate(reversed(range(dm.T - first_step - num_steps, dm.T - first_step))):
         t = torch.full((B,), i, dtype=torch.long)
@@ -352,10 +360,10 @@ def sample_chain(sd, dm, init_pos, init_v, batch, shape, num_steps, noise_fn, ke
         pos, v, log_v0, log_post = posterior_step(sd, dm, pos, v, pr["pred_ligand_pos"], pr["pred_ligand_v"],
                                                   batch, t, eps, u)
         if keep_traj:
-            out["pos_traj"].append(pos.clone()); out["v_traj"].append(v.clone())
+            out["pos_traj"].append(pos + offset); out["v_traj"].append(v.clone())
             out["v0_traj"].append(log_v0); out["vt_traj"].append(log_post)
             out["pos_cond_traj"].append(pr["pred_ligand_pos"]); out["v_cond_traj"].append(pr["pred_ligand_v"])
-    out["pos"], out["v"] = pos, v
+    out["pos"], out["v"] = pos + offset, v
     return out
 
 

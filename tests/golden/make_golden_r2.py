@@ -16,6 +16,7 @@ because these take tens of CPU-minutes while make_golden.py's set regenerates in
     python tests/golden/make_golden_r2.py retall        # round 3: forward(return_all=True)
     python tests/golden/make_golden_r2.py b256_tail     # round 3: the last 49 steps of the b256 chain in 10-step snapshots (minutes)
     python tests/golden/make_golden_r2.py b1024_s1000   # round 3: configs[2]/[3] per-GPU batch at full length (~3 CPU-hours)
+    python tests/golden/make_golden_r2.py center        # round 3: sample_diffusion(center_pos_mode='center') on off-centre molecules (seconds)
 
 Noise is the hash noise of synth.step_noise (a pure function of (seed, step)), so the fixtures
 hold only the states: end pos / v, snapshots, and the first steps (so that the CPU suite can
@@ -64,6 +65,24 @@ def chain(model, tag, B, S, seed, every, head, atoms_range=None, max_atoms=None,
         pos0_first=r["pos_cond_traj"][0].numpy(), v0_first=r["v0_traj"][0].numpy(),
         vt_last=r["vt_traj"][-1].numpy(), **extra)
     print(f"chain {tag}: N = {n}, {S} steps in {time.time() - t0:.0f} s", flush=True)
+
+
+def center_fixture(model):
+    """sample_diffusion(center_pos_mode='center') (molopt_score_model.py:52-60,547,675-684) on molecules moved away from the
+    origin: 6 molecules, 30 steps, hash noise; every trajectory kept (small)."""
+    B, S, seed = 6, 30, 41
+    bb = synth.synthetic_batch(B, seed=seed)
+    n = len(bb["batch"])
+    shift = (synth.hash_normal((B, 3), 911, seed) * 4.0).astype(np.float32)
+    init = (bb["init_pos"] + shift[bb["batch"]]).astype(np.float32)
+    eps, u = zip(*[synth.step_noise(n, 15, s, seed=seed) for s in range(S)])
+    with G.fed_noise(list(eps), list(u)), contextlib.redirect_stdout(open(os.devnull, "w")):
+        r = model.sample_diffusion(t_(init), t_(bb["init_v"]), t_(bb["batch"]), t_(bb["shape"]).view(B, -1), num_steps=S,
+                                   center_pos_mode="center")
+    np.savez_compressed(os.path.join(HERE, "chain_center_b6_s30_hash.npz"), B=B, S=S, seed=seed, init_pos=init, pos=r["pos"].numpy(),
+                        v=r["v"].numpy(), pos_traj=torch.stack(r["pos_traj"]).numpy(), v_traj=torch.stack(r["v_traj"]).numpy().astype(np.int8),
+                        pos_cond_traj=torch.stack(r["pos_cond_traj"]).numpy())
+    print(f"center: N = {n}, {S} steps, |pos| max {float(r['pos'].abs().max()):.2f}", flush=True)
 
 
 def chain_tail(model, src_tag, tag, max_atoms=None, every=10):
@@ -313,6 +332,11 @@ def main():
         if what in ("b256", "all"):
             use_threads("b256")
             chain(model, "b256_s1000", 256, 1000, 13, every=50, head=4, max_atoms=38)
+    if what in ("center", "all"):        # round 3
+        torch.set_num_threads(8)
+        model, _ = G.load_reference_model()
+        G.synthetic_load(model, seed=7)
+        center_fixture(model)
     if what in ("loss", "all"):
         use_threads("loss")
         loss_fixture()

@@ -1309,3 +1309,22 @@ def test_chain_center_pos_mode_center():
     assert maxabs(torch.stack(res["pos_cond_traj"]).cpu(), torch.stack(base["pos_cond_traj"]).cpu().numpy()) < 2e-5
     with pytest.raises(NotImplementedError):
         m.sample_diffusion(T(moved, DEV), T(c["init_v"], DEV), T(c["batch"], DEV), T(c["shape"], DEV).view(4, -1), num_steps=2, center_pos_mode="mass")
+
+
+def test_chain_center_pos_mode_golden():
+    """center_pos_mode='center' against the reference's own run on off-centre molecules (chain_center_b6_s30_hash.npz): atom
+    types exact at every step, `pos` / `pos_traj` (offset restored) and `pos_cond_traj` (centred frame) within 1e-4."""
+    from util import record
+    m = hip_model()
+    c = golden("chain_center_b6_s30_hash.npz")
+    B, S, seed = int(c["B"]), int(c["S"]), int(c["seed"])
+    bb = synth.synthetic_batch(B, seed=seed)
+    eps, u = hash_noise(len(bb["batch"]), S, seed)
+    r = m.sample_diffusion(T(c["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV).view(B, -1), num_steps=S,
+                           center_pos_mode="center", noise=(T(eps, DEV), T(u, DEV)))
+    assert np.array_equal(r["v"].cpu().numpy(), c["v"])
+    assert np.array_equal(torch.stack(r["v_traj"]).numpy(), c["v_traj"])
+    e = dict(pos=maxabs(r["pos"], c["pos"]), pos_traj=maxabs(torch.stack(r["pos_traj"]), c["pos_traj"]),
+             pos_cond_traj=maxabs(torch.stack(r["pos_cond_traj"]), c["pos_cond_traj"]))
+    record("chain_center_pos_mode_golden", **e)
+    assert max(e.values()) < POS_TOL, e

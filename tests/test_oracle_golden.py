@@ -80,6 +80,22 @@ def test_chain_hash_noise(tag):
     assert maxabs(torch.stack(r["pos_traj"][::every]), c["pos_traj_sub"]) < 1e-4
 
 
+def test_chain_center_pos_mode_oracle_golden():
+    """center_pos_mode='center' (off-centre molecules, 30 steps) against the reference's own run."""
+    sd, dm, _, _ = oracle_model()
+    c = golden("chain_center_b6_s30_hash.npz")
+    B, S, seed = int(c["B"]), int(c["S"]), int(c["seed"])
+    bb = synth.synthetic_batch(B, seed=seed)
+    n = len(bb["batch"])
+    r = O.sample_chain(sd, dm, T(c["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S,
+                       lambda s: synth.step_noise(n, 15, s, seed=seed), center=True)
+    assert np.array_equal(r["v"].numpy(), c["v"])
+    assert np.array_equal(torch.stack(r["v_traj"]).numpy(), c["v_traj"])
+    assert maxabs(r["pos"], c["pos"]) < 1e-4
+    assert maxabs(torch.stack(r["pos_traj"]), c["pos_traj"]) < 1e-4
+    assert maxabs(torch.stack(r["pos_cond_traj"]), c["pos_cond_traj"]) < 1e-4
+
+
 def test_guidance_function_golden():
     """The oracle's point-cloud guidance against the reference function's output (sklearn KD-tree, numpy) on the
     recorded draws: the same atoms move, to the same float32 positions."""
