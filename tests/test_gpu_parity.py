@@ -310,7 +310,7 @@ def test_error_reporting():
     with pytest.raises(NotImplementedError):
         m.sample_diffusion(torch.zeros(3, 3, device=DEV), torch.zeros(3, dtype=torch.long, device=DEV),
                            torch.zeros(3, dtype=torch.long, device=DEV), torch.zeros(1, 96, device=DEV),
-                           num_steps=2, center_pos_mode="center")
+                           num_steps=2, use_mesh_data=object())
 
 
 def test_sampling_driver_layout_and_equivalence():
