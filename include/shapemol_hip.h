@@ -169,7 +169,7 @@ void shapemol_se_destroy(shapemol_se_ctx *ctx);
 /* d_points (B,N,3) f32 DEVICE, N a multiple of 16; d_out (B,latent_dim,3) f32 DEVICE. */
 int shapemol_se_encode(shapemol_se_ctx *ctx, const float *d_points, int64_t n_shapes, int64_t n_points, float *d_out, void *stream);
 
-/* ---- training building block (first milestone of the backward pass) -----------------------
+/* ---- training building blocks (the operators of a layer, forward and backward) ---------------
  * The MLP block of models/common.py:47-67 -- y = W2 relu(LayerNorm(W1 x + b1)) + b2, eps 1e-5, affine LayerNorm -- forward
  * with the quantities its backward needs, and the backward: what torch.autograd does for the 58 MLPs of one score
  * evaluation when scripts/train_diffusion.py:135-147 calls loss.backward().  fp32 arithmetic (fp32 MFMA products), device

@@ -1,4 +1,4 @@
-// Training building block (first milestone of the backward pass): the MLP block of the score
+// Training building blocks (the backward pass).  First: the MLP block of the score
 // network -- Linear -> LayerNorm(eps 1e-5, affine) -> ReLU -> Linear, /root/reference/models/common.py:47-67, the shared
 // inner block of every edge and node function (58 of them per evaluation, ~95 % of its FLOPs) -- forward WITH the
 // quantities its backward needs, and the backward itself: gradients of the input rows and of all six parameter tensors.
@@ -11,8 +11,9 @@
 // Arithmetic: fp32 throughout, products on v_mfma_f32_16x16x4_f32 (exact fp32 multiply-add), so that gradients can be
 // held to 1e-4 of the reference's (tests/golden/grad_b12.npz).  Reductions over the rows (the parameter gradients) are
 // deterministic: every workgroup writes a partial, a second kernel adds the partials in a fixed order (no atomics).
-// These kernels are a correct first version of the training path, not a tuned one: one generic strided GEMM serves all
-// five products (rows x small, small x small with the reduction over the rows split over workgroups).
+// One strided GEMM (two kernels: float4 operand moves where strides and alignment allow, scalar otherwise) serves all five
+// products (rows x small, small x small with the reduction over the rows split over workgroups).  Further down: the edge
+// form's gather / segment sums, the segment attention and the vector-neuron coordinate update, each forward and backward.
 #pragma once
 #include "sm_device.h"
 

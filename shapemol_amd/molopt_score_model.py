@@ -289,8 +289,8 @@ class ScorePosNet3D(nn.Module):
         per molecule.  Same arguments and result dict.  Under torch.no_grad() -- the form validate() runs
         (scripts/train_diffusion.py:168-192, module in eval mode, which switches the batch-norm to its running statistics) --
         the score evaluation is the HIP sampling path.  With autograd enabled -- the training step,
-        scripts/train_diffusion.py:135-147 -- it is the differentiable evaluation of shapemol_amd.training (every MLP block
-        forward and backward in HIP, the glue in torch device ops; first milestone of the backward pass), so that
+        scripts/train_diffusion.py:135-147 -- it is the differentiable evaluation of shapemol_amd.training (every operator of a
+        layer forward and backward in HIP; graph construction, distance features and embeddings in torch device ops), so that
         ``result['loss'].backward()`` fills ``.grad`` of every parameter (gate: tests/golden/grad_b12.npz, the reference's own
         gradients).
 

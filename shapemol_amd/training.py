@@ -1,4 +1,4 @@
-"""Training step on the device (first milestone of the backward pass).
+"""Training step on the device (the backward pass).
 
 What the reference's ``scripts/train_diffusion.py:135-147`` needs from the model is ``get_diffusion_loss(...)['loss']``
 with autograd recording, so that ``loss.backward()`` fills ``.grad`` of every parameter.  The sampling path of this package
