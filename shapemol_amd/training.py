@@ -288,11 +288,27 @@ def _vn_update(P, B, p, x, o3, shape, batch, training):
     return out
 
 
+def _named_tensors(model):
+    """name -> Parameter and name -> buffer maps of the model.  ``dict(model.named_parameters())`` walks the module tree (the
+    model is a tree of ~400 small holders: 2.8 ms per call, a tenth of a training step); the (name, holder module, leaf)
+    triples are kept on the model instead and the tensors looked up in their holders on every call, so that parameters or
+    buffers replaced by ``.to()`` / ``load_state_dict(assign=True)`` are seen."""
+    slots = model.__dict__.get("_tensor_slots")
+    if slots is None:
+        slots = ([], [])
+        for prefix, mod in model.named_modules():
+            dot = prefix + "." if prefix else ""
+            slots[0].extend((dot + leaf, mod, leaf) for leaf in mod._parameters)
+            slots[1].extend((dot + leaf, mod, leaf) for leaf in mod._buffers)
+        model.__dict__["_tensor_slots"] = slots
+    return ({name: mod._parameters[leaf] for name, mod, leaf in slots[0] if mod._parameters[leaf] is not None},
+            {name: mod._buffers[leaf] for name, mod, leaf in slots[1] if mod._buffers[leaf] is not None})
+
+
 def score_with_grad(model, pos, v, batch, shape, t):
     """One score evaluation recorded by autograd; same result dict as ``ScorePosNet3D.forward``."""
     dm = model.dims
-    P = dict(model.named_parameters())
-    Bf = dict(model.named_buffers())
+    P, Bf = _named_tensors(model)
     lin = lambda p, x: F.linear(x, P[p + ".weight"], P[p + ".bias"])  # noqa: E731
     n = pos.shape[0]
     # time embedding (molopt_score_model.py:154-166,247-252) and atom embedding (:292-301)
