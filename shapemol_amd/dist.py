@@ -81,3 +81,36 @@ def gather_molecules(pos, v, counts, group=None, _single_rank_too=False, plan=No
     out_v = g.index_select(0, plan.v_idx).to(torch.int64)
     out_c = g.index_select(0, plan.c_idx).to(torch.int64)
     return out_p.to(out_dev), out_v.to(out_dev), out_c.to(out_dev)
+
+
+def sample_diffusion_ligand_sharded(model, shape_emb, num_samples, batch_size=16, *, job_seed, group=None, **kw):
+    """One sampling job (``scripts/sample_diffusion.py:47-162`` for one shape condition) spread over the ranks of a process group.
+
+    The job's ``ceil(num_samples / batch_size)`` batches -- the chunks the reference loops over, each coupled internally by the
+    batch-norm and independent of the others -- are dealt to the ranks in contiguous blocks (:func:`shard_batches`); every rank
+    runs its batches through :func:`shapemol_amd.sampling.sample_diffusion_ligand` (two chains in flight, trajectories delivered
+    to this rank's host), and ONE collective at the end gathers the generated molecules.  Every batch's host random numbers
+    (atom counts, initial positions, the chain's noise key) are keyed by ``job_seed + batch index``: the molecules of the job do
+    not depend on the number of ranks.
+
+    Returns ``(outputs, pred_pos, pred_v)``: ``outputs`` = the reference's 9-tuple for THIS rank's batches (trajectories stay
+    rank-local, as the reference writes one result file per process), ``pred_pos`` / ``pred_v`` = per-molecule arrays of the
+    WHOLE job in job order, identical on every rank.  ``kw``: the other arguments of ``sample_diffusion_ligand``."""
+    import numpy as np
+    from .sampling import sample_diffusion_ligand
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
+    num_batch = -(-int(num_samples) // int(batch_size))
+    mine = shard_batches(num_batch, rank, world)
+    out = sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=batch_size, _batches=mine, _batch_seed=int(job_seed), **kw)
+    pred_pos, pred_v = out[0], out[1]
+    if not on or world == 1:
+        return out, pred_pos, pred_v
+    dev = torch.device(kw.get("device", "cuda:0"))
+    counts = torch.tensor([len(x) for x in pred_v], dtype=torch.int64, device=dev)
+    pos = torch.from_numpy(np.concatenate(pred_pos) if pred_pos else np.zeros((0, 3))).to(torch.float32).to(dev)   # float32 on the device: lossless
+    v = torch.from_numpy(np.concatenate(pred_v) if pred_v else np.zeros((0,), np.int64)).to(torch.int64).to(dev)
+    g_pos, g_v, g_counts = gather_molecules(pos, v, counts, group=group)
+    cum = np.concatenate([[0], np.cumsum(g_counts.cpu().numpy())])
+    g_pos, g_v = g_pos.cpu().numpy().astype(np.float64), g_v.cpu().numpy()
+    return out, [g_pos[cum[k]:cum[k + 1]] for k in range(len(cum) - 1)], [g_v[cum[k]:cum[k + 1]] for k in range(len(cum) - 1)]

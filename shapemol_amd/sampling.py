@@ -104,7 +104,7 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
                             pos_only=False, center_pos_mode="none", sample_func=None, threshold_type=None,
                             threshold_args=None, sample_num_atoms="prior", bounds=None, ref_num_atoms=None,
                             ref_atom_feature=None, guide_stren=0, seed=None, use_graph=True, host_rng=False,
-                            use_pointcloud_data=None, grad_step=1000, pipeline=2):
+                            use_pointcloud_data=None, grad_step=1000, pipeline=2, _batches=None, _batch_seed=None):
     """``sample_diffusion_ligand`` of the reference for one shape condition.
 
     shape_emb        (32, 3) latent of the condition (``data.shape_emb``); repeated per molecule of a batch.
@@ -130,6 +130,11 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
                      noise), the random draws are made in batch order, and results are returned in batch order, so the output
                      does not depend on this value.  ``time_list`` then holds each batch's wall time from its enqueue to its
                      delivery, which overlaps its neighbours'.
+
+    _batches, _batch_seed   private to ``shapemol_amd.dist.sample_diffusion_ligand_sharded``: the indices of the job's batches
+                     this call runs (default: all), and a job seed that keys every batch's host random numbers (numpy's and
+                     torch's generators are reseeded with ``_batch_seed + batch index`` before the batch's draws), so that a batch's
+                     molecules do not depend on which rank runs it.
 
     Returns the reference's 9-tuple: ``(pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj,
     time_list, pred_pos_cond_traj, pred_v_cond_traj)``; positions are float64 host arrays, as there.
@@ -180,9 +185,12 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
             all_pred_vt_traj += take("vt_traj")
         time_list.append(time.time() - t1)
 
-    for i in range(num_batch):
+    for slot_i, i in enumerate(range(num_batch) if _batches is None else _batches):
         n_data = batch_size if i < num_batch - 1 else num_samples - batch_size * (num_batch - 1)
         t1 = time.time()
+        if _batch_seed is not None:
+            np.random.seed((int(_batch_seed) + i) % (2 ** 32))
+            torch.manual_seed(int(_batch_seed) + i)
         if sample_num_atoms == "size":
             assert sample_func is not None
             ligand_num_atoms = [int(x) for x in sample_func(n_data)]
@@ -226,7 +234,7 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
             center_pos_mode=center_pos_mode, guide_stren=guide_stren, bounds=bounds,
             use_pointcloud_data=use_pointcloud_data, grad_step=grad_step,
             seed=None if seed is None else int(seed) + i, use_graph=use_graph, **noise_kw,
-            **({"_reuse_host_buffers": "device", "_slot": i % depth, "_async": True} if accelerated else {}))
+            **({"_reuse_host_buffers": "device", "_slot": slot_i % depth, "_async": True} if accelerated else {}))
         pending.append((handle, ligand_num_atoms, n_data, t1))
     while pending:
         deliver(pending.popleft())

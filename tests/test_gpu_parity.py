@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI) against the golden vectors of the reference and
 against the CPU oracle on the same inputs.  Run on the GPU box:  pytest tests -m gpu"""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -1328,3 +1329,52 @@ def test_chain_center_pos_mode_golden():
              pos_cond_traj=maxabs(torch.stack(r["pos_cond_traj"]), c["pos_cond_traj"]))
     record("chain_center_pos_mode_golden", **e)
     assert max(e.values()) < POS_TOL, e
+
+
+def _sharded_job(**kw):
+    from shapemol_amd.dist import sample_diffusion_ligand_sharded
+    m = hip_model()
+    shape_emb = synth.synthetic_batch(1, seed=5)["shape"][0]
+    return sample_diffusion_ligand_sharded(m, shape_emb, 11, batch_size=3, job_seed=77, num_steps=8, sample_num_atoms="size",
+                                           sample_func=lambda n: np.random.randint(9, 20, n).tolist(), device="cuda:0", **kw)
+
+
+def _sharded_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out, pos, v = _sharded_job()
+        q.put((rank, len(out[0]), len(out[2]), [np.array(p) for p in pos], [np.array(x) for x in v]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sampling_job_two_ranks_equals_one():
+    """shapemol_amd.dist.sample_diffusion_ligand_sharded: a job of 11 molecules in batches of 3 run by two processes (gloo between
+    them, both on this GPU: the collectives of the rehearsal path go through the host) gathers, on both ranks, exactly the
+    molecules the same job gives in one process -- a batch's random numbers are keyed by the job seed and its index, not by the
+    rank that runs it -- while trajectories stay with the rank that produced them."""
+    import socket
+    import torch.multiprocessing as mp
+    _, pos1, v1 = _sharded_job()
+    assert len(pos1) == 11 and all(len(p) == len(x) for p, x in zip(pos1, v1))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [6, 5] and [g[2] for g in got] == [6, 5]       # own molecules / own trajectories: batches {0, 1} and {2, 3}
+    for _, _, _, pos2, v2 in got:
+        assert len(pos2) == 11
+        for a_, b_ in zip(pos1, pos2):
+            assert np.array_equal(a_, b_)
+        for a_, b_ in zip(v1, v2):
+            assert np.array_equal(a_, b_)
