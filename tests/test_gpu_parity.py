@@ -1378,3 +1378,28 @@ def test_sharded_sampling_job_two_ranks_equals_one():
             assert np.array_equal(a_, b_)
         for a_, b_ in zip(v1, v2):
             assert np.array_equal(a_, b_)
+
+
+def test_forward_and_chain_b4096_vs_oracle():
+    """Four times the largest BASELINE batch on one GPU (4096 MOSES-sized molecules, 88 k atoms, 0.7 M edges: 64-bit offsets,
+    grids of thousands of workgroups, looping edge launches with ~340 jobs per workgroup): one evaluation and one chain step
+    against the CPU oracle (the oracle's two evaluations at this size are ~90 s of the test)."""
+    from util import record
+    m = hip_model()
+    sd, dm, _, _ = oracle_model()
+    B = 4096
+    bb = synth.synthetic_batch(B, seed=4097, max_atoms=38)
+    n = len(bb["batch"])
+    t = (synth.hash_u24(B, 80, 3) % 1000).astype(np.int64)
+    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    with torch.no_grad():
+        out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
+    errs = {k: maxabs(out[k], ref[k]) for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v")}
+    S = 1
+    eps, u = hash_noise(n, S, 4097)
+    r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
+    ro = O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S, lambda s_: (eps[s_], u[s_]), keep_traj=False)
+    errs["chain_pos"] = maxabs(r["pos"], ro["pos"])
+    record("forward_and_chain_b4096_vs_oracle", n_atoms=n, **errs)
+    assert np.array_equal(r["v"].cpu().numpy(), ro["v"].numpy())
+    assert max(errs.values()) < FWD_TOL, errs
