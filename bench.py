@@ -318,7 +318,7 @@ def main():
                 rj.load_batch(bj["init_pos"], bj["init_v"], bj["batch"], bj["shape"])
                 runners.append(rj)
             for r_ in runners:
-                r_.run(max(warm, 5), seed=21, use_graph=True)
+                r_.run(max(warm, 5, min(clock_warm, r_.max_steps)), seed=21, use_graph=True)
             for r_ in runners:
                 r_.synchronize()
             torch.cuda.synchronize()
@@ -339,7 +339,7 @@ def main():
             model.set_option("edge_bf16", 1)
             model.set_option("node_f16", 0)
             try:
-                runner.run(max(1, min(warm, es)), seed=31, use_graph=True)       # re-captures the step graph with these kernels
+                runner.run(max(1, min(warm, es), min(clock_warm, runner.max_steps)), seed=31, use_graph=True)   # re-captures the step graph with these kernels; loaded clocks
                 runner.synchronize()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
@@ -358,7 +358,7 @@ def main():
             es = min(args.exact_steps, runner.max_steps)
             model.set_option("feat_f16", 1)
             try:
-                runner.run(max(1, min(warm, es)), seed=41, use_graph=True)
+                runner.run(max(1, min(warm, es), min(clock_warm, runner.max_steps)), seed=41, use_graph=True)
                 runner.synchronize()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
