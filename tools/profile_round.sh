@@ -7,7 +7,7 @@ set -eo pipefail
 OUT=${1:-gpurun_out/prof_round}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-SHORT="--steps 20 --warmup 5 --cpu-steps 0 --profile-steps 2 --eager --concurrent 0 --exact-steps 0"
+SHORT="--steps 20 --warmup 5 --clock-warmup 0 --cpu-steps 0 --profile-steps 2 --eager --concurrent 0 --exact-steps 0"
 find_csv() { find "$1" -name "*$2" | head -1; }
 
 for B in 256 1024; do
