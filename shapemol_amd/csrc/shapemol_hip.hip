@@ -9,6 +9,7 @@
 #include "sm_edge16.h"
 #include "sm_node.h"
 #include "sm_node16.h"
+#include "sm_edge_stream.h"
 #include "sm_misc.h"
 #include <hip/hip_ext.h>
 
@@ -129,6 +130,9 @@ struct DevLayer {
     size_t blob_x2h, blob_h2x;        // fp32 edge kernels (sm_edge.h): both MLPs of a kernel in one LDS image
     size_t img_kx, img_vx, img_kh, img_vh;   // bf16-split phase kernels (sm_edge_bf16.h): one image per MLP
     size_t i16_kx, i16_vx, i16_kh, i16_vh;   // two-piece f16 images (sm_edge16.h)
+    size_t st_kx, st_vx, st_kh, st_vh;       // streaming kernels (sm_edge_stream.h): producer parts (LDS images) ...
+    size_t sw2_kx, sw2_vx, sw2_kh;           // ... and the second Linears as three bf16 pieces (consumers' registers)
+    size_t sb2_vx;                           // bias of the x2h value MLP's second Linear [H]
     size_t vn_f, vn_d;                // original [heads][cin]
     size_t wf_x, wd_x, wf_o, wd_o, bn_g, bn_b;
 };
@@ -375,6 +379,75 @@ size_t pack_linear16_image(Image &im, size_t src, int rows, int K) {
     return o;
 }
 
+// one edge MLP -> the producer part of the streaming kernels (StreamMap<H, .>::P_*, sm_edge_stream.h): RBF block of the first
+// Linear as three bf16 pieces (three words of the K = 32 step: centres 0..5 of lane group g in words 0..2), gamma, beta, b2 and,
+// for the heads-wide value MLP of h2x, the second Linear (rows = heads in natural order, padded to 16)
+template <int H>
+size_t pack_stream_part(Image &im, const Mlp &m, int kv_in, bool h2x_value) {
+    constexpr int NT = H / 16, NB = NT / 2;
+    using MX = StreamMap<H, false>; using MH = StreamMap<H, true>;
+    const int total = h2x_value ? MH::PART_V : MX::PART_K;
+    const size_t o = im.alloc(total);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&im.d[o]);
+    std::memset(d, 0, (size_t)total * 4);
+    for (int t = 0; t < NT; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int q = 0; q < 3; ++q) {
+                uint16_t pc[2][3];
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * q + e;
+                    split3_host(j < 5 ? m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * j + (lane >> 4)] : 0.f, pc[e]);
+                }
+                for (int piece = 0; piece < 3; ++piece)
+                    d[MX::P_W1 + ((size_t)(piece * NT + t) * 64 + lane) * 3 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+            }
+    float *pp = &im.d[o];
+    std::memcpy(pp + MX::P_G, m.g, H * sizeof(float));
+    std::memcpy(pp + MX::P_B, m.be, H * sizeof(float));
+    std::memcpy(pp + MX::P_B2, m.l2.b, std::min(m.l2.out, H) * sizeof(float));
+    if (h2x_value) {
+        for (int b = 0; b < NB; ++b)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = lane & 15, g = lane >> 4;
+                for (int q = 0; q < 4; ++q) {
+                    uint16_t pc[2][3];
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * q + e;
+                        const int col = 16 * (2 * b + (j >> 2)) + 4 * g + (j & 3);
+                        split3_host(row < m.l2.out ? m.l2.w[(size_t)row * H + col] : 0.f, pc[e]);
+                    }
+                    for (int piece = 0; piece < 3; ++piece)
+                        d[MH::P_W2 + (((size_t)piece * NB + b) * 64 + lane) * 4 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+                }
+            }
+    }
+    return o;
+}
+
+// second Linear [H][H] of an edge MLP as three bf16 pieces [3][NT][NB][64][4] u32, element order of gemm_bf16x6 (rows natural)
+template <int H>
+size_t pack_stream_w2(Image &im, const Mlp &m) {
+    constexpr int NT = H / 16, NB = NT / 2;
+    const size_t o = im.alloc((size_t)3 * NT * NB * 256);
+    uint32_t *w2 = reinterpret_cast<uint32_t *>(&im.d[o]);
+    for (int t2 = 0; t2 < NT; ++t2)
+        for (int b = 0; b < NB; ++b)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = 16 * t2 + (lane & 15), g = lane >> 4;
+                for (int q = 0; q < 4; ++q) {
+                    uint16_t pc[2][3];
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * q + e;
+                        const int col = 16 * (2 * b + (j >> 2)) + 4 * g + (j & 3);
+                        split3_host(m.l2.w[(size_t)row * H + col], pc[e]);
+                    }
+                    for (int piece = 0; piece < 3; ++piece)
+                        w2[(((size_t)(piece * NT + t2) * NB + b) * 64 + lane) * 4 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+                }
+            }
+    return o;
+}
+
 template <int H>
 int build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, DevLayer &D, float &hid_max) {
     const int G = c.num_r_gaussian, SL = c.shape_latent_dim, S = c.shape_dim, hd = c.n_heads;
@@ -419,6 +492,10 @@ int build_layer_image(const shapemol_config &c, const HostLayer &L, Image &im, D
     hid_max = std::max(hid_max, pack_image16<H>(im, L.hv, kv, false, D.i16_vx));
     hid_max = std::max(hid_max, pack_image16<H>(im, L.xk, kv, false, D.i16_kh));
     hid_max = std::max(hid_max, pack_image16<H>(im, L.xv, kv, true, D.i16_vh));
+    D.st_kx = pack_stream_part<H>(im, L.hk, kv, false); D.st_vx = pack_stream_part<H>(im, L.hv, kv, false);
+    D.st_kh = pack_stream_part<H>(im, L.xk, kv, false); D.st_vh = pack_stream_part<H>(im, L.xv, kv, true);
+    D.sw2_kx = pack_stream_w2<H>(im, L.hk); D.sw2_vx = pack_stream_w2<H>(im, L.hv); D.sw2_kh = pack_stream_w2<H>(im, L.xk);
+    D.sb2_vx = im.put(L.hv.l2.b, H);
     D.vn_f = im.put(L.vn_f, (size_t)hd * cin); D.vn_d = im.put(L.vn_d, (size_t)hd * cin);
     D.bn_g = im.put(L.bn_g, hd); D.bn_b = im.put(L.bn_b, hd);
     D.wf_x = im.alloc(hd); D.wd_x = im.alloc(hd); D.wf_o = im.alloc((size_t)hd * 16); D.wd_o = im.alloc((size_t)hd * 16);
@@ -594,12 +671,14 @@ int ensure_workspace(shapemol_ctx *c, int64_t N, int64_t B) {
     return 0;
 }
 
+static int stream_chunk(const shapemol_ctx *c, int n_atoms);
 constexpr int kVnFoldBytes = kVnFoldCap * 3 * 4 + 32 * 8;      // LDS of the folded coordinate update: table + batch sums
 
 // can the coordinate update of a layer be folded into the next x2h kernel?  f16 one-job (or sliced) edge kernels, the
 // VN-linear + statistics epilogue in h2x, and every workgroup's molecule span inside the LDS table
 bool vn_fold_ok(const shapemol_ctx *c, int n_atoms) {
-    if (!c->vn_fold || c->edge_bf16 != 3 || c->KP > 16 || c->vn_fuse != 2 || c->max_mol_atoms <= 0) return false;
+    if (!c->vn_fold || (c->edge_bf16 != 3 && c->edge_bf16 != 2) || c->KP > 16 || c->vn_fuse != 2 || c->max_mol_atoms <= 0) return false;
+    if (c->edge_bf16 == 2) return stream_chunk(c, n_atoms) * (16 / c->KP) + 2 * (c->max_mol_atoms - 1) <= kVnFoldCap;
     const int apj = 16 / c->KP, njobs = (n_atoms + apj - 1) / apj;
     const int waves = std::max(4, std::min(12, (njobs + c->num_cu - 1) / c->num_cu));
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
@@ -654,7 +733,11 @@ int set_edge_attr(int KP) {
     HIPCHK(hipFuncSetAttribute((const void *)edge16_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge16_loop_kernel<H, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (EdgeImage16<H, H / 16>::TOTAL + EdgeImage16<H, 1>::TOTAL) * 4 + vn_red_doubles(12, H / 8) * 8 + 12 * 96 * 4));
-    if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) } else { SETATTR6(32) }
+#define SETATTR7(K)                                                                                                   \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_stream_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, StreamMap<H, false>::O_TAIL * 4 + kVnFoldBytes)); \
+    HIPCHK(hipFuncSetAttribute((const void *)edge_stream_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, StreamMap<H, true>::O_TAIL * 4 + (H / 16 + kStreamProducers) * 64 * 2 * 8));
+    if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) SETATTR7(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) SETATTR7(16) } else { SETATTR6(32) }
+#undef SETATTR7
 #undef SETATTR6
 #undef SETATTR4
 #undef SETATTR3
@@ -758,6 +841,30 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
         }
     }
 #undef EDGE_DISPATCH
+    return 0;
+}
+
+// streaming edge kernels (sm_edge_stream.h; option edge_bf16 = 2): consecutive tiles per workgroup -- every CU one workgroup,
+// whole rounds
+static int stream_chunk(const shapemol_ctx *c, int n_atoms) {
+    const int apj = 16 / c->KP, njobs = (n_atoms + apj - 1) / apj;
+    const int per_cu = (njobs + c->num_cu - 1) / c->num_cu;
+    return std::max(kStreamTPR, (per_cu + kStreamTPR - 1) / kStreamTPR * kStreamTPR);
+}
+
+template <int H, bool H2X>
+int launch_stream(shapemol_ctx *c, hipStream_t s, EdgeStreamArgs a) {
+    const int KP = c->KP;
+    if (KP > 16) return fail("k > 16 has no streaming edge kernel (option edge_bf16 = 2 needs k <= 16)");
+    const int apj = 16 / KP, njobs = (a.n_atoms + apj - 1) / apj;
+    a.chunk = stream_chunk(c, a.n_atoms);
+    const int grid = (njobs + a.chunk - 1) / a.chunk;
+    using M = StreamMap<H, H2X>;
+    constexpr int NWAVE = H / 16 + kStreamProducers;
+    const size_t shm = (size_t)M::O_TAIL * 4 + (H2X ? (size_t)NWAVE * 64 * 2 * 8 : (a.vf.enable ? (size_t)kVnFoldBytes : 0));
+    const char *nm = H2X ? "edge_h2x" : "edge_x2h";
+    if (KP == 8) LAUNCH(nm, SMK((edge_stream_kernel<H, 8, H2X>), dim3(grid), dim3(NWAVE * 64), shm, s, a));
+    else LAUNCH(nm, SMK((edge_stream_kernel<H, 16, H2X>), dim3(grid), dim3(NWAVE * 64), shm, s, a));
     return 0;
 }
 
@@ -933,6 +1040,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         const bool last = (l == nlay - 1), has_next = !last;
         const bool phases = c->edge_bf16 && KP <= 16;
         const bool f16 = c->edge_bf16 == 3;     // two-piece f16 operands (sm_edge16.h), the default
+        const bool stream = c->edge_bf16 == 2 && KP <= 16;      // exactly split bf16 operands, streaming kernels (sm_edge_stream.h)
         const bool xc_fused = f16 && x2h_chain_ok<H>(c, n);
         const bool half_tiles = f16 && KP > 16;          // k > 16: two 16-slot tiles per atom + combine
         Edge16Args xea{};
@@ -945,6 +1053,15 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             if (half_tiles) { ea.out = c->part_rows; ea.part_ms = c->part_ms; }       // k > 16: per-tile rows, merged below
             if (!xc_fused && launch_edge16<H, false>(c, s, ea)) return 1;     // (fused: launched with the node stage below)
             if (half_tiles && launch_combine32<false>(c, s, c->att, n)) return 1;
+        } else if (stream) {   // x2h attention, exactly split bf16 operands, producer / consumer waves (sm_edge_stream.h)
+            EdgeStreamArgs sa{};
+            sa.part_k = c->P(Dl.st_kx); sa.part_v = c->P(Dl.st_vx);
+            sa.w2k = reinterpret_cast<const unsigned *>(c->P(Dl.sw2_kx)); sa.w2v = reinterpret_cast<const unsigned *>(c->P(Dl.sw2_vx));
+            sa.b2v = c->P(Dl.sb2_vx);
+            sa.pre = l == 0 ? c->pre0 : c->preAB + 4 * H; sa.q = c->q_x; sa.x = cur_x; sa.nbr = c->nbr; sa.ew = c->ew; sa.out = c->att;
+            sa.n_atoms = n; sa.ld_pre = l == 0 ? 4 * H : 8 * H; sa.stamps = (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr;
+            sa.vf = pending; pending = VnFold{};
+            if (launch_stream<H, false>(c, s, sa)) return 1;
         } else if (phases && c->edge_bf16 == 1) {   // x2h attention, key and value phase in one launch
             EdgeFusedArgs fa{c->P(Dl.img_kx), c->P(Dl.img_vx), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew,
                              c->alpha, c->att, n, l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
@@ -1010,6 +1127,29 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             }
             if (launch_edge16<H, true>(c, s, ea)) return 1;
             if (half_tiles && launch_combine32<true>(c, s, c->o3, n)) return 1;
+        } else if (stream && c->vn_fuse != 1) {   // h2x attention (+ VN-linear and batch statistics when vn_fuse = 2), streaming kernel
+            EdgeStreamArgs sa{};
+            sa.part_k = c->P(Dl.st_kh); sa.part_v = c->P(Dl.st_vh);
+            sa.w2k = reinterpret_cast<const unsigned *>(c->P(Dl.sw2_kh));
+            sa.pre = c->preAB; sa.q = c->q_h; sa.x = cur_x; sa.nbr = c->nbr; sa.ew = c->ew; sa.out = c->o3;
+            sa.n_atoms = n; sa.ld_pre = 8 * H; sa.stamps = (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr;
+            if (c->vn_fuse) {
+                sa.vn = {c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o), c->P(Dl.wd_o),
+                         c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd,
+                         nullptr, c->status + ST_VN_BARRIER, x_next, 2};
+                stats_done = true;
+                if (fold && has_next) {      // no vn_apply launch: the next x2h kernel finishes the update
+                    sa.xsum = c->xsum;
+                    pending = VnFold{c->pd, stat_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, x_next,
+                                     c->mol_span, c->status + ST_SPAN, 1};
+                    vn_done = true;
+                } else if (fold && last && l == L - 1 && out_pos && c->ddpm_fold && c->g_points == 0 && C <= 16 && hd <= 16) {
+                    sa.xsum = c->xsum;
+                    c->ddpm_vf = DdpmFold{c->pd, stat_acc + (size_t)l * kBnReplicas * 2 * hd, c->P(Dl.bn_g), c->P(Dl.bn_b), c->xsum, cur_x, out_pos, hd, 1};
+                    vn_done = true;
+                }
+            }
+            if (launch_stream<H, true>(c, s, sa)) return 1;
         } else if (phases) {   // h2x attention, both images resident in LDS (exactly split bf16 operands)
             EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H,
                              (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
@@ -1324,7 +1464,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     }
     if (k == "stop_layer") c->stop_layer = (int)value;
     else if (k == "edge_bf16") {
-        if (value != 0 && value != 1 && value != 3) return fail("edge_bf16 must be 0 (fp32 MFMA), 1 (exactly split bf16) or 3 (two-piece f16)");
+        if (value < 0 || value > 3) return fail("edge_bf16 must be 0 (fp32 MFMA), 1 (exactly split bf16, phase kernels), 2 (exactly split bf16, streaming kernels) or 3 (two-piece f16)");
         if (value != 3 && c->KP > 16) return fail("k > 16 runs on the two-piece f16 edge kernels only (edge_bf16 = 3)");
         if (value == 3 && c->hid_max > 6.0e4f) return fail("edge_bf16 = 3: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights");
         c->edge_bf16 = (int)value;

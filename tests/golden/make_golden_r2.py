@@ -17,6 +17,7 @@ because these take tens of CPU-minutes while make_golden.py's set regenerates in
     python tests/golden/make_golden_r2.py b256_tail     # round 3: the last 49 steps of the b256 chain in 10-step snapshots (minutes)
     python tests/golden/make_golden_r2.py b1024_s1000   # round 3: configs[2]/[3] per-GPU batch at full length (~3 CPU-hours)
     python tests/golden/make_golden_r2.py center        # round 3: sample_diffusion(center_pos_mode='center') on off-centre molecules (seconds)
+    python tests/golden/make_golden_r2.py b256_pins     # round 4: the b256 chain again, recording the reference's neighbour lists where the k-th / (k+1)-th choice is fragile
 
 Noise is the hash noise of synth.step_noise (a pure function of (seed, step)), so the fixtures
 hold only the states: end pos / v, snapshots, and the first steps (so that the CPU suite can
@@ -116,6 +117,65 @@ def chain_tail(model, src_tag, tag, max_atoms=None, every=10):
     first = (-done) % every
     np.savez_compressed(os.path.join(HERE, f"chain_{tag}_hash.npz"), src=src_tag, first_step=done + first, every=every,
                         pos_traj_tail=pos_traj[first::every], v_traj_tail=v_traj[first::every].astype(np.int8))
+
+
+def chain_pins(model, src_tag, tag, max_atoms=None, thr=5e-4):
+    """Re-run a committed full-length chain and record the reference's kNN choice wherever it is FRAGILE: centre atoms whose
+    k-th and (k+1)-th candidates lie within a relative margin `thr` in squared distance (models/uni_transformer.py:446-473;
+    one graph per score evaluation, :499).  A second float32 implementation whose coordinates differ in the last bits picks
+    the other candidate there and leaves the reference's trajectory for good; with the choice pinned
+    at exactly these (step, atom) pairs a free-running chain can be held to the reference over all 1000 steps.  Sparse table
+    (step, atom, nbr[k], margin): KBs.  Self-check: the end state must reproduce the committed chain bit for bit."""
+    import models.uni_transformer as ut
+    c = np.load(os.path.join(HERE, f"chain_{src_tag}_hash.npz"))
+    B, S, seed = int(c["B"]), int(c["S"]), int(c["seed"])
+    bb = synth.synthetic_batch(B, seed=seed, max_atoms=max_atoms)
+    n = len(bb["batch"])
+    counts = [int(x) for x in bb["counts"]]
+    real_knn = ut.knn_graph
+    rec = dict(step=[], atom=[], nbr=[], margin=[], calls=0, min_margin=[])
+
+    def spy(x, k, batch=None, **kw):
+        e = real_knn(x, k=k, batch=batch, **kw)
+        step, start, lo = rec["calls"], 0, np.inf
+        for cnt in counts:
+            if cnt - 1 > k:
+                p = x[start:start + cnt]
+                d = p[:, None, :] - p[None, :, :]
+                d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]        # the stand-in's arithmetic (make_golden.knn_graph)
+                d2 = (d2 + d[..., 2] * d[..., 2]).clone()
+                d2.fill_diagonal_(float("inf"))
+                val, order = torch.sort(d2, dim=1, stable=True)
+                m = ((val[:, k] - val[:, k - 1]) / val[:, k - 1]).numpy()
+                lo = min(lo, float(m.min()))
+                for a in np.nonzero(m < thr)[0]:
+                    rec["step"].append(step)
+                    rec["atom"].append(start + int(a))
+                    rec["nbr"].append((order[a, :k] + start).numpy().astype(np.int32))
+                    rec["margin"].append(float(m[a]))
+            start += cnt
+        rec["min_margin"].append(lo)
+        rec["calls"] += 1
+        return e
+
+    eps, u = zip(*[synth.step_noise(n, 15, s, seed=seed) for s in range(S)])
+    t0 = time.time()
+    ut.knn_graph = spy
+    try:
+        with G.fed_noise(list(eps), list(u)), contextlib.redirect_stdout(open(os.devnull, "w")):
+            r = model.sample_diffusion(t_(bb["init_pos"]), t_(bb["init_v"]), t_(bb["batch"]),
+                                       t_(bb["shape"]).view(B, -1), num_steps=S, center_pos_mode="none")
+    finally:
+        ut.knn_graph = real_knn
+    same = np.array_equal(r["pos"].numpy(), c["pos"]) and np.array_equal(r["v"].numpy(), c["v"])
+    print(f"chain_pins {tag}: {rec['calls']} graphs, {len(rec['step'])} fragile (step, atom) pairs below {thr:g}, "
+          f"{time.time() - t0:.0f} s; end state reproduces the committed chain bit for bit: {same}", flush=True)
+    # the pins are recorded against THIS run's edges: verify the pinned rows are what the reference's graph held
+    np.savez_compressed(os.path.join(HERE, f"chain_{tag}_pins.npz"), src=src_tag, thr=thr, reproduces_committed_chain=same,
+                        step=np.asarray(rec["step"], np.int16), atom=np.asarray(rec["atom"], np.int16),
+                        nbr=np.stack(rec["nbr"]).astype(np.int16) if rec["nbr"] else np.zeros((0, 8), np.int16),
+                        margin=np.asarray(rec["margin"], np.float32), min_margin_per_step=np.asarray(rec["min_margin"], np.float32))
+    assert same, "the re-run must reproduce the committed end state (same BLAS thread count as the full chain?)"
 
 
 class GuideRecorder:
@@ -313,13 +373,16 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     # float32 reductions of the CPU BLAS depend on the thread count: every fixture records the count it was made with
     # (the 47-minute B=256 chain ran on 6 threads beside a build, the k=32 set on 3), and a regeneration uses the same
-    threads = {"b256": 6, "b1024": 8, "k32": 3, "guide": 8, "se": 8, "loss": 8, "b256_tail": 6, "b1024_s1000": 5, "b512_k32": 6, "grad": 8}
+    threads = {"b256_pins": 6, "b256": 6, "b1024": 8, "k32": 3, "guide": 8, "se": 8, "loss": 8, "b256_tail": 6, "b1024_s1000": 5, "b512_k32": 6, "grad": 8}
     def use_threads(task):
         torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", threads[task])))
     torch.set_num_threads(8)
-    if what in ("b256", "b1024", "b256_tail", "b1024_s1000", "all"):
+    if what in ("b256", "b1024", "b256_tail", "b1024_s1000", "b256_pins", "all"):
         model, _ = G.load_reference_model()
         G.synthetic_load(model, seed=7)
+        if what == "b256_pins":          # (not part of "all": a second 20-47 minute run of the b256 chain) round 4
+            use_threads("b256_pins")
+            chain_pins(model, "b256_s1000", "b256_s1000", max_atoms=38)
         if what == "b256_tail":          # (not part of "all": derived from the committed b256 chain, minutes)
             use_threads("b256_tail")
             chain_tail(model, "b256_s1000", "b256_s1000_tail", max_atoms=38)
