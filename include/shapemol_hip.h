@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SHAPEMOL_ABI_VERSION 4
+#define SHAPEMOL_ABI_VERSION 5
 
 typedef struct shapemol_ctx shapemol_ctx;
 
@@ -242,9 +242,12 @@ int shapemol_seg_attention_backward(const float *d_q, const float *d_k, const fl
  *                        state given as d_init_pos / d_init_v; noise and trajectory rows stay indexed from 0; default 0.
  *                        Used by the windowed full-length parity test; the reference always starts at T-1),
  *          "stop_layer" (run only the first v layers of the next _score; -1 = all),
- *          "edge_bf16"  (3 = fused key/value edge kernel on two-piece f16 operands, both MLP images resident [default];
- *                        1 = fused kernel on exactly split bf16 operands (six products, weight swap between the phases;
- *                        k <= 16), 0 = fp32-MFMA edge kernels),
+ *          "edge_bf16"  (3 = fused key/value edge kernel on two-piece f16 operands, both MLP images resident;
+ *                        2 = streaming kernels on exactly split bf16 operands (three pieces = the 24 bits of fp32, six products):
+ *                            weights stationary in the registers of consumer waves, producer waves stream edge tiles through
+ *                            LDS (sm_edge_stream.h; k <= 16) -- the reference-precision path;
+ *                        1 = fused phase kernel on exactly split bf16 operands (weight swap between the phases; k <= 16),
+ *                        0 = fp32-MFMA edge kernels),
  *          "node_f16"   (1 = node kernels (prologue, chain, per-node products) on two-piece f16 operands [default]: the
  *                        residual stream then passes through fp16 pieces, |x| >= 6e4 raises a status flag;
  *                        0 = the same kernels on exactly split bf16 operands, six products per term),
@@ -280,6 +283,15 @@ int shapemol_seg_attention_backward(const float *d_q, const float *d_k, const fl
  *          "stamps", "kstamp_sel" (clock-stamp diagnostics; only meaningful in the --stamps build).
  * Changing an option invalidates a captured graph (the next _sample re-captures). */
 int shapemol_set_option(shapemol_ctx *ctx, const char *name, int64_t value);
+/* Diagnostic of the parity tests: pin the kNN graph of the following _sample calls at given (reverse step, atom) pairs to given
+ * neighbour lists (the reference's own, recorded where its k-th / (k+1)-th choice is closer than a float32 implementation can
+ * reproduce: models/uni_transformer.py:446-473 builds one graph per score evaluation, and a flipped neighbour sends the molecule
+ * down another trajectory for good).  h_off: HOST [n_steps + 1] CSR offsets of the pins of reverse step s = 0 .. n_steps - 1
+ * (s = num_timesteps - 1 - t); h_atom [n_pins] atom index; h_nbr [n_pins][k] neighbour indices (global atom indices, the
+ * reference's order).  n_pins = 0 removes the pins.  While pins are set the graph is built by the separate kNN / edge-weight
+ * launches (the pinned rows are overwritten between them). */
+int shapemol_set_knn_pins(shapemol_ctx *ctx, const int32_t *h_off, int32_t n_steps, const int32_t *h_atom, const int32_t *h_nbr,
+                          int64_t n_pins, int32_t k);
 /* Copy an internal device buffer of the last _score to HOST memory (synchronises the device).
  * names: "nbr" (N,KP) i32, "ew" (N,KP) f32, "h" (N,H), "x" (N,3), "pre" (N,4H), "q" (N,H),
  *        "att" (N,H), "o3" (N,48), "bnstat" (L,16,2,heads) f64, "dims" (8,) i64,

@@ -12,6 +12,9 @@ if [[ "${1:-}" == "--report" ]]; then
    | c++filt | cut -c1-160
 elif [[ "${1:-}" == "--ablate" ]]; then     # diagnostic: drop phases of the edge kernel at compile time (mask in $2)
   hipcc $FLAGS -DSM_ABLATE=$2 -o ../libshapemol_hip_abl$2.so shapemol_hip.hip shape_encoder.hip train_ops.hip
+elif [[ "${1:-}" == "--variant" ]]; then    # experiment builds (tools/ only): build.sh --variant NAME -DFLAG=1 ... -> ../libshapemol_hip_NAME.so (SHAPEMOL_LIB=NAME)
+  name=$2; shift 2
+  hipcc $FLAGS "$@" -o ../libshapemol_hip_${name}.so shapemol_hip.hip shape_encoder.hip train_ops.hip
 elif [[ "${1:-}" == "--stamps-serial" ]]; then
   hipcc $FLAGS -DSM_STAMPS -DSM_STAMPS_SERIAL -o ../libshapemol_hip_stamps.so shapemol_hip.hip shape_encoder.hip train_ops.hip
 elif [[ "${1:-}" == "--stamps" ]]; then     # diagnostic build with in-kernel phase stamps (tools/ only)

@@ -547,7 +547,7 @@ struct shapemol_ctx {
     int64_t lastN = 0, lastB = 0;
     const float *last_h = nullptr, *last_x = nullptr;
     // options
-    int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 3, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
+    int stop_layer = -1, edge_threads = 0 /* 0 = chosen per launch */, lin_waves = 16, edge_bf16 = 2, lin_bf16 = 1, chain_bf16 = 1, vn_fuse = 2;
     int vn_fold = 1;            // coordinate update of layer l in the prologue of the x2h kernel of layer l + 1 (needs max_mol_atoms)
     int max_mol_atoms = 0;      // largest molecule of the batches to come (option; 0 = unknown: no fold)
     int lin_fuse = 0;           // 1: per-node products of the next attentions inside node_chain16_kernel instead of a node_linear
@@ -559,7 +559,7 @@ struct shapemol_ctx {
     int graph_fuse = 1;         // 1: kNN graph + edge weights in one launch (graph_kernel) when max_mol_atoms <= kGraphCap is known
     int x2h_chain = 1;          // 1: x2h attention and the node stage of a layer in one launch (x2h_chain16_kernel) when every wave has one job
                                 // launch (measured: 28.5 us against 15.3 + 11.1 us, eight dependent weight blocks per wave)
-    int node_f16 = 1;           // node kernels on two-piece f16 operands (sm_node16.h) instead of exactly split bf16 (sm_node.h)
+    int node_f16 = 0;           // 1: node kernels on two-piece f16 operands (sm_node16.h) instead of exactly split bf16 (sm_node.h) [default 0]
     int feat_f16 = 0;           // 1: "f16 features" -- matrix products on the leading f16 piece only (one product per term instead of
                                 // three; accumulation, LayerNorm, softmax, coordinates fp32).  Reduced precision, NOT a parity mode
     int edge_tiles = -1;        // f16 edge kernels when the waves have several jobs: 0 = sliced launches of the one-job kernel,
@@ -569,6 +569,8 @@ struct shapemol_ctx {
     // point-cloud shape guidance (shapemol_set_guidance)
     double *g_cloud = nullptr; int64_t g_points = 0; double g_radius = 0.0; int g_grad_step = 0; const double *g_draws = nullptr;
     int first_step = 0;         // option "first_step": the next chains start at reverse step first_step (t = T-1-first_step)
+    // diagnostic: neighbour lists pinned at given (reverse step, atom) pairs (shapemol_set_knn_pins)
+    int *pin_off = nullptr, *pin_atom = nullptr, *pin_nbr = nullptr; int64_t n_pins = 0; int pin_steps = 0, pin_k = 0;
     // profiling
     bool prof_on = false;
     std::vector<ProfRec> prof;
@@ -678,7 +680,7 @@ constexpr int kVnFoldBytes = kVnFoldCap * 3 * 4 + 32 * 8;      // LDS of the fol
 // VN-linear + statistics epilogue in h2x, and every workgroup's molecule span inside the LDS table
 bool vn_fold_ok(const shapemol_ctx *c, int n_atoms) {
     if (!c->vn_fold || (c->edge_bf16 != 3 && c->edge_bf16 != 2) || c->KP > 16 || c->vn_fuse != 2 || c->max_mol_atoms <= 0) return false;
-    if (c->edge_bf16 == 2) return stream_chunk(c, n_atoms) * (16 / c->KP) + 2 * (c->max_mol_atoms - 1) <= kVnFoldCap;
+    if (c->edge_bf16 == 2) return stream_chunk(c, n_atoms) * (16 / c->KP) + 2 * (c->max_mol_atoms - 1) <= kVnFoldCap;      // (KP <= 16 here)
     const int apj = 16 / c->KP, njobs = (n_atoms + apj - 1) / apj;
     const int waves = std::max(4, std::min(12, (njobs + c->num_cu - 1) / c->num_cu));
     const int grid = std::max(1, std::min(c->num_cu, (njobs + waves - 1) / waves));
@@ -736,7 +738,7 @@ int set_edge_attr(int KP) {
 #define SETATTR7(K)                                                                                                   \
     HIPCHK(hipFuncSetAttribute((const void *)edge_stream_kernel<H, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, StreamMap<H, false>::O_TAIL * 4 + kVnFoldBytes)); \
     HIPCHK(hipFuncSetAttribute((const void *)edge_stream_kernel<H, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, StreamMap<H, true>::O_TAIL * 4 + (H / 16 + kStreamProducers) * 64 * 2 * 8));
-    if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) SETATTR7(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) SETATTR7(16) } else { SETATTR6(32) }
+    if (KP == 8) { SETATTR(8) SETATTR3(8) SETATTR4(8) SETATTR7(8) } else if (KP == 16) { SETATTR(16) SETATTR3(16) SETATTR4(16) SETATTR7(16) } else { SETATTR6(32) SETATTR7(32) }
 #undef SETATTR7
 #undef SETATTR6
 #undef SETATTR4
@@ -846,17 +848,18 @@ int launch_edge16(shapemol_ctx *c, hipStream_t s, const Edge16Args &a) {
 
 // streaming edge kernels (sm_edge_stream.h; option edge_bf16 = 2): consecutive tiles per workgroup -- every CU one workgroup,
 // whole rounds
+static int stream_jobs(const shapemol_ctx *c, int n_atoms) {      // a job = one 16-slot tile: 16 / KP atoms, or half an atom (k > 16)
+    return c->KP > 16 ? 2 * n_atoms : (n_atoms + 16 / c->KP - 1) / (16 / c->KP);
+}
 static int stream_chunk(const shapemol_ctx *c, int n_atoms) {
-    const int apj = 16 / c->KP, njobs = (n_atoms + apj - 1) / apj;
+    const int njobs = stream_jobs(c, n_atoms);
     const int per_cu = (njobs + c->num_cu - 1) / c->num_cu;
     return std::max(kStreamTPR, (per_cu + kStreamTPR - 1) / kStreamTPR * kStreamTPR);
 }
 
 template <int H, bool H2X>
 int launch_stream(shapemol_ctx *c, hipStream_t s, EdgeStreamArgs a) {
-    const int KP = c->KP;
-    if (KP > 16) return fail("k > 16 has no streaming edge kernel (option edge_bf16 = 2 needs k <= 16)");
-    const int apj = 16 / KP, njobs = (a.n_atoms + apj - 1) / apj;
+    const int KP = c->KP, njobs = stream_jobs(c, a.n_atoms);
     a.chunk = stream_chunk(c, a.n_atoms);
     const int grid = (njobs + a.chunk - 1) / a.chunk;
     using M = StreamMap<H, H2X>;
@@ -864,7 +867,8 @@ int launch_stream(shapemol_ctx *c, hipStream_t s, EdgeStreamArgs a) {
     const size_t shm = (size_t)M::O_TAIL * 4 + (H2X ? (size_t)NWAVE * 64 * 2 * 8 : (a.vf.enable ? (size_t)kVnFoldBytes : 0));
     const char *nm = H2X ? "edge_h2x" : "edge_x2h";
     if (KP == 8) LAUNCH(nm, SMK((edge_stream_kernel<H, 8, H2X>), dim3(grid), dim3(NWAVE * 64), shm, s, a));
-    else LAUNCH(nm, SMK((edge_stream_kernel<H, 16, H2X>), dim3(grid), dim3(NWAVE * 64), shm, s, a));
+    else if (KP == 16) LAUNCH(nm, SMK((edge_stream_kernel<H, 16, H2X>), dim3(grid), dim3(NWAVE * 64), shm, s, a));
+    else LAUNCH(nm, SMK((edge_stream_kernel<H, 32, H2X>), dim3(grid), dim3(NWAVE * 64), shm, s, a));
     return 0;
 }
 
@@ -950,6 +954,19 @@ NodeFollow follow_of(const shapemol_ctx *c, const DevMlpImg &m, int mode, float 
 }
 
 // Step-invariant per-batch quantities (molecule index, invariant shape embedding, shape terms)
+// Diagnostic (shapemol_set_knn_pins): overwrite the neighbour rows of the atoms pinned at the current reverse step with the
+// given lists.  off [steps + 1] CSR offsets per reverse step, atom [n], pnbr [n][k].
+__global__ void knn_pin_kernel(const int *off, int n_steps, const int *atom, const int *pnbr, int k, int kp, const int *step_cur, int n_atoms, int *nbr) {
+    const int step = *step_cur;
+    if (step < 0 || step >= n_steps) return;
+    const int lo = off[step], hi = off[step + 1];
+    for (int e = lo + blockIdx.x * blockDim.x + threadIdx.x; e < hi; e += gridDim.x * blockDim.x) {
+        const int i = atom[e];
+        if (i < 0 || i >= n_atoms) continue;
+        for (int sl = 0; sl < kp; ++sl) nbr[(size_t)i * kp + sl] = sl < k ? pnbr[(size_t)e * k + sl] : -1;
+    }
+}
+
 template <int H>
 int run_prep(shapemol_ctx *c, hipStream_t s, const int64_t *d_batch, int64_t N, int64_t B, const float *d_shape) {
     const shapemol_config &g = c->cfg;
@@ -999,7 +1016,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         LAUNCH("embed", SMK(atom_embed_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, ae));
     }
     // (chains only: the hint is set for the batch of a chain; a score evaluation on other data must not trust a stale one)
-    const bool graph_fused = sampling && c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap && KP <= 32;
+    const bool graph_fused = sampling && c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap && KP <= 32 && c->n_pins == 0;
     if (graph_fused) {
         GraphArgs ga{x_in, c->mol_span, n, g.knn, KP, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
                      c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, c->status + ST_SPAN, c->kstamp_sel == 4 ? c->kstamps : nullptr};
@@ -1008,6 +1025,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         else if (KP == 16) LAUNCH("graph", SMK((graph_kernel<H, 16>), dim3((n + apb - 1) / apb), dim3(kGraphWaves * 64), 0, s, ga));
         else LAUNCH("graph", SMK((graph_kernel<H, 32>), dim3((n + apb - 1) / apb), dim3(kGraphWaves * 64), 0, s, ga));
     } else LAUNCH("knn", SMK(knn_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x_in, c->mol_of, c->mol_off, n, g.knn, KP, c->nbr));
+    if (sampling && c->n_pins > 0)      // diagnostic: the pinned atoms of this reverse step take the given neighbour lists
+        LAUNCH("knn", SMK(knn_pin_kernel, dim3(32), dim3(256), 0, s, c->pin_off, c->pin_steps, c->pin_atom, c->pin_nbr, c->pin_k, KP, c->steps + 1, n, c->nbr));
     EdgeWeightArgs ea{x_in, c->nbr, c->P(c->dm.ew.w1), c->P(c->dm.ew.b1), c->P(c->dm.ew.g), c->P(c->dm.ew.be),
                       c->P(c->dm.ew.w2), c->P(c->dm.ew.b2), c->ew, n * KP, KP};
     if (!graph_fused) {
@@ -1040,9 +1059,9 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
         const bool last = (l == nlay - 1), has_next = !last;
         const bool phases = c->edge_bf16 && KP <= 16;
         const bool f16 = c->edge_bf16 == 3;     // two-piece f16 operands (sm_edge16.h), the default
-        const bool stream = c->edge_bf16 == 2 && KP <= 16;      // exactly split bf16 operands, streaming kernels (sm_edge_stream.h)
+        const bool stream = c->edge_bf16 == 2;      // exactly split bf16 operands, streaming kernels (sm_edge_stream.h)
         const bool xc_fused = f16 && x2h_chain_ok<H>(c, n);
-        const bool half_tiles = f16 && KP > 16;          // k > 16: two 16-slot tiles per atom + combine
+        const bool half_tiles = (f16 || c->edge_bf16 == 2) && KP > 16;          // k > 16: two 16-slot tiles per atom + combine
         Edge16Args xea{};
         if (f16) {   // x2h attention: both MLP images resident, one barrier
             Edge16Args &ea = xea;
@@ -1061,7 +1080,9 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             sa.pre = l == 0 ? c->pre0 : c->preAB + 4 * H; sa.q = c->q_x; sa.x = cur_x; sa.nbr = c->nbr; sa.ew = c->ew; sa.out = c->att;
             sa.n_atoms = n; sa.ld_pre = l == 0 ? 4 * H : 8 * H; sa.stamps = (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr;
             sa.vf = pending; pending = VnFold{};
+            if (half_tiles) { sa.out = c->part_rows; sa.part_ms = c->part_ms; }       // k > 16: per-tile rows, merged below
             if (launch_stream<H, false>(c, s, sa)) return 1;
+            if (half_tiles && launch_combine32<false>(c, s, c->att, n)) return 1;
         } else if (phases && c->edge_bf16 == 1) {   // x2h attention, key and value phase in one launch
             EdgeFusedArgs fa{c->P(Dl.img_kx), c->P(Dl.img_vx), l == 0 ? c->pre0 : c->preAB + 4 * H, c->q_x, cur_x, c->nbr, c->ew,
                              c->alpha, c->att, n, l == 0 ? 4 * H : 8 * H, (c->kstamp_sel == 1 && l == 0) ? c->kstamps : nullptr};
@@ -1133,7 +1154,8 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
             sa.w2k = reinterpret_cast<const unsigned *>(c->P(Dl.sw2_kh));
             sa.pre = c->preAB; sa.q = c->q_h; sa.x = cur_x; sa.nbr = c->nbr; sa.ew = c->ew; sa.out = c->o3;
             sa.n_atoms = n; sa.ld_pre = 8 * H; sa.stamps = (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr;
-            if (c->vn_fuse) {
+            if (half_tiles) { sa.out = c->part_rows; sa.part_ms = c->part_ms; }       // (no fused VN-linear: vn_stats / vn_apply below)
+            if (c->vn_fuse && !half_tiles) {
                 sa.vn = {c->ps + (size_t)l * c->capB * 2 * hd * 3, c->P(Dl.wf_x), c->P(Dl.wd_x), c->P(Dl.wf_o), c->P(Dl.wd_o),
                          c->P(Dl.bn_g), c->P(Dl.bn_b), c->mol_of, c->pd, c->bn_acc + (size_t)l * kBnReplicas * 2 * hd,
                          nullptr, c->status + ST_VN_BARRIER, x_next, 2};
@@ -1150,6 +1172,7 @@ int run_score(shapemol_ctx *c, hipStream_t s, const float *x_in, const int64_t *
                 }
             }
             if (launch_stream<H, true>(c, s, sa)) return 1;
+            if (half_tiles && launch_combine32<true>(c, s, c->o3, n)) return 1;
         } else if (phases) {   // h2x attention, both images resident in LDS (exactly split bf16 operands)
             EdgeFusedArgs fa{c->P(Dl.img_kh), c->P(Dl.img_vh), c->preAB, c->q_h, cur_x, c->nbr, c->ew, c->alpha, c->o3, n, 8 * H,
                              (c->kstamp_sel == 2 && l == 0) ? c->kstamps : nullptr};
@@ -1302,10 +1325,8 @@ int shapemol_create(const shapemol_config *cfg, const float *weights, size_t n_w
         hipLaunchKernelGGL(emb_table_kernel, dim3((items + 255) / 256), dim3(256), 0, nullptr, c->P(dm.embwT), c->P(dm.embb), c->ttab, c->etab, T, C, cfg->time_emb_dim, H);
         if (hipDeviceSynchronize() != hipSuccess) { hipFree(c->etab); hipFree(c->ttab); hipFree(c->d_img); delete c; return fail("embedding table kernel failed"); }
     }
-    if (c->hid_max > 6.0e4f) {      // hidden activations could overflow fp16: exactly split bf16 kernels (k <= 16 only)
-        if (c->KP > 16) { shapemol_destroy(c); return fail("shapemol_create: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights, and k > 16 has no bf16 path"); }
-        c->edge_bf16 = 1;
-    }
+    // (the default kernels split every operand into bf16 pieces, which have the fp32 exponent range: no bound on the weights.  The
+    //  optional two-piece f16 kernels, edge_bf16 = 3, refuse weights whose LayerNorm outputs could leave the fp16 range: hid_max)
     *out = c;
     return 0;
 }
@@ -1323,6 +1344,7 @@ void shapemol_destroy(shapemol_ctx *c) {
     if (c->g_cloud) hipFree(c->g_cloud);
     if (c->bn_run) hipFree(c->bn_run);
     if (c->bn_eval_acc) hipFree(c->bn_eval_acc);
+    if (c->pin_off) { hipFree(c->pin_off); hipFree(c->pin_atom); hipFree(c->pin_nbr); }
     delete c;
 }
 
@@ -1401,7 +1423,7 @@ int shapemol_sample(shapemol_ctx *c, const float *d_init_pos, const int64_t *d_i
     if (use_graph && !c->prof_on) {
         shapemol_ctx::GraphKey key{};
         key.N = N; key.B = B; key.guided = c->g_points > 0; key.fold = vn_fold_ok(c, (int)N);
-        key.gfuse = c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap;
+        key.gfuse = c->graph_fuse && c->max_mol_atoms > 0 && c->max_mol_atoms <= kGraphCap && c->n_pins == 0;
         // two executables: one reverse step, and kGraphUnroll steps back to back (the gap between two graph launches,
         // ~8 us, is then paid once per kGraphUnroll steps); every step reads its index from the device-side counter
         auto capture = [&](int n_steps, hipGraphExec_t *exec) -> int {
@@ -1465,7 +1487,7 @@ int shapemol_set_option(shapemol_ctx *c, const char *name, int64_t value) {
     if (k == "stop_layer") c->stop_layer = (int)value;
     else if (k == "edge_bf16") {
         if (value < 0 || value > 3) return fail("edge_bf16 must be 0 (fp32 MFMA), 1 (exactly split bf16, phase kernels), 2 (exactly split bf16, streaming kernels) or 3 (two-piece f16)");
-        if (value != 3 && c->KP > 16) return fail("k > 16 runs on the two-piece f16 edge kernels only (edge_bf16 = 3)");
+        if (value != 3 && value != 2 && c->KP > 16) return fail("k > 16 runs on the streaming (edge_bf16 = 2) or the two-piece f16 (edge_bf16 = 3) edge kernels");
         if (value == 3 && c->hid_max > 6.0e4f) return fail("edge_bf16 = 3: the edge MLPs' LayerNorm outputs may exceed the fp16 range for these weights");
         c->edge_bf16 = (int)value;
     }
@@ -1520,6 +1542,25 @@ int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t
     if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("shapemol_debug_read: copy failed"); return -1; }
     return (int64_t)bytes;
+}
+
+int shapemol_set_knn_pins(shapemol_ctx *c, const int32_t *h_off, int32_t n_steps, const int32_t *h_atom, const int32_t *h_nbr, int64_t n_pins, int32_t k) {
+    if (!c) return fail("shapemol_set_knn_pins: null context");
+    HIPCHK(hipSetDevice(c->device));
+    c->drop_graphs();
+    HIPCHK(hipDeviceSynchronize());
+    if (c->pin_off) { hipFree(c->pin_off); hipFree(c->pin_atom); hipFree(c->pin_nbr); c->pin_off = c->pin_atom = c->pin_nbr = nullptr; }
+    c->n_pins = 0; c->pin_steps = 0; c->pin_k = 0;
+    if (n_pins <= 0) return 0;
+    if (!h_off || !h_atom || !h_nbr || n_steps < 1 || k < 1 || k > c->KP) return fail("shapemol_set_knn_pins: bad arguments");
+    if (h_off[0] != 0 || h_off[n_steps] != n_pins) return fail("shapemol_set_knn_pins: offsets do not cover the pins");
+    for (int i = 0; i < n_steps; ++i) if (h_off[i + 1] < h_off[i]) return fail("shapemol_set_knn_pins: offsets must not decrease");
+    HIPCHK(hipMalloc(&c->pin_off, (size_t)(n_steps + 1) * 4)); HIPCHK(hipMalloc(&c->pin_atom, (size_t)n_pins * 4)); HIPCHK(hipMalloc(&c->pin_nbr, (size_t)n_pins * k * 4));
+    HIPCHK(hipMemcpy(c->pin_off, h_off, (size_t)(n_steps + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->pin_atom, h_atom, (size_t)n_pins * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->pin_nbr, h_nbr, (size_t)n_pins * k * 4, hipMemcpyHostToDevice));
+    c->n_pins = n_pins; c->pin_steps = n_steps; c->pin_k = k;
+    return 0;
 }
 
 int shapemol_set_guidance(shapemol_ctx *c, const double *h_cloud, int64_t n_points, double radius, int32_t grad_step, const double *d_draws) {

@@ -46,9 +46,20 @@ struct EdgeStreamArgs {
     EdgeFusedArgs::VnFuse vn;         // h2x: VN-linear + batch statistics behind the attention (enable = 0 or 2)
     float *xsum;                      // h2x with vn.enable: [N][3] sum of the attention rows per atom (for a following fold), or nullptr
     VnFold vf;                        // x2h: coordinate update of the previous layer in the prologue
+    float *part_ms;                   // KP = 32: [2 N][heads][2] running max and sum of every half-atom tile's softmax (sm_edge16.h)
 };
 
 constexpr int kStreamProducers = 4, kStreamTPR = 2;      // producer waves; tiles per round
+#ifndef SM_STREAM_EARLY
+#define SM_STREAM_EARLY 0        // experiment: request the next unit's rows right after the current rows are summed
+#endif
+#ifndef SM_STREAM_ABL
+#define SM_STREAM_ABL 0          // timing attribution builds only (bit 0: consumers skip their matrix products, 1: producers skip the
+#endif                           // first Linear's products, 2: producers skip LayerNorm, 3: producers skip the split, 4: no s_setprio for producers)
+#define SM_SABL(bit) (((SM_STREAM_ABL) >> (bit)) & 1)
+#ifndef SM_STREAM_TOUCH
+#define SM_STREAM_TOUCH 0        // experiment: consumers warm the L2 with the later rounds' rows while the producers work on round 0
+#endif
 
 // dynamic LDS map in 32-bit words
 template <int H, bool H2X>
@@ -82,6 +93,7 @@ SM_DEV int stream_row_of_head(int head) {
 
 SM_DEV f32x4 mfma_bf16x6(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &xh, const u32x4 &xm, const u32x4 &xl,
                          f32x4 &small, f32x4 big) {
+    if (SM_SABL(0)) { big[0] += __builtin_bit_cast(float, ah[0] ^ am[1] ^ al[2] ^ xh[3] ^ xm[0] ^ xl[1]); return big; }
     small = mfma_bf16(al, xh, small);      // the three terms of order 2 in one chain ...
     small = mfma_bf16(am, xm, small);
     small = mfma_bf16(ah, xl, small);
@@ -91,16 +103,58 @@ SM_DEV f32x4 mfma_bf16x6(const u32x4 &ah, const u32x4 &am, const u32x4 &al, cons
     return big;
 }
 
+// LayerNorm (eps 1e-5, biased variance, two-pass) + ReLU of one D-layout column vector, as ln_relu_dlayout (sm_device.h), written
+// for a wave that has the SIMD's vector pipe to itself (a producer): the two reductions run as four independent partial sums
+// (eight-term chains instead of 32-term ones -- a lone wave pays the full latency of every dependent instruction), gamma and beta
+// come from LDS.
+template <int NT>
+SM_DEV void ln_relu_stream(float (&v)[NT * 4], const float *gamma, const float *beta, int g) {
+    constexpr int H = NT * 16, W = NT >= 4 ? 4 : NT;
+    float ps[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) ps[w] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT * 4; ++i) ps[i % W] += v[i];
+    float s = ps[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) s += ps[w];
+    const float mean = sum_groups(s) * (1.0f / H);
+    float pq[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) pq[w] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT * 4; ++i) { const float d = v[i] - mean; pq[i % W] += d * d; }
+    float q = pq[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) q += pq[w];
+    const float var = sum_groups(q) * (1.0f / H);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 ga = ldg4(gamma + 16 * t + 4 * g);
+        const float4 be = ldg4(beta + 16 * t + 4 * g);
+        v[4 * t + 0] = fmaxf((v[4 * t + 0] - mean) * rstd * ga.x + be.x, 0.f);
+        v[4 * t + 1] = fmaxf((v[4 * t + 1] - mean) * rstd * ga.y + be.y, 0.f);
+        v[4 * t + 2] = fmaxf((v[4 * t + 2] - mean) * rstd * ga.z + be.z, 0.f);
+        v[4 * t + 3] = fmaxf((v[4 * t + 3] - mean) * rstd * ga.w + be.w, 0.f);
+    }
+}
+
 // geometry of a launch, shared by the roles
 template <int H, int KP, bool H2X>
 struct StreamGeo {
     static constexpr int NT = H / 16, NB = NT / 2, TPR = kStreamTPR, NCONS = NT, NWAVE = NT + kStreamProducers;
-    static constexpr int SEGW = KP, APJ = 16 / SEGW, HD = H / 8;
+    static constexpr bool HALF = KP == 32;                       // k > 16: a tile is half an atom (sm_edge16.h), merged by combine32_kernel
+    static constexpr int SEGW = KP >= 16 ? 16 : KP, APJ = 16 / SEGW, HD = H / 8;
+    // tile geometry: column n of tile t is neighbour slot slot_of(t, n) of centre atom atom_of(t, n)
+    SM_DEV static int atom_of(int tile, int n) { return HALF ? (tile >> 1) : tile * APJ + n / SEGW; }
+    SM_DEV static int slot_of(int tile, int n) { return HALF ? 16 * (tile & 1) + n : n % SEGW; }
+    SM_DEV static int first_atom_of(int tile) { return HALF ? (tile >> 1) : tile * APJ; }
     int lane, wave, n, g, wg_first, wg_end, rounds;
     SM_DEV StreamGeo(const EdgeStreamArgs &a) {
         lane = threadIdx.x & 63; wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         n = lane & 15; g = lane >> 4;
-        const int njobs = (a.n_atoms + APJ - 1) / APJ;
+        const int njobs = HALF ? 2 * a.n_atoms : (a.n_atoms + APJ - 1) / APJ;
         wg_first = blockIdx.x * a.chunk; wg_end = min(njobs, wg_first + a.chunk);
         rounds = (wg_end - wg_first + TPR - 1) / TPR;
     }
@@ -272,18 +326,18 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
     int atom = 0, jn = 0, jraw_nx = -1;
     bool ok = false;
     auto tile_of = [&](int r) { return wg_first + TPR * r + my_slot; };
-    auto peek = [&](int tile) { return a.nbr[min(tile * APJ + n / SEGW, a.n_atoms - 1) * KP + n % SEGW]; };
+    auto peek = [&](int tile) { return a.nbr[min(GE::atom_of(tile, n), a.n_atoms - 1) * KP + GE::slot_of(tile, n)]; };
     auto request = [&](int tile, int jraw) {
-        const int atom_raw = tile * APJ + n / SEGW;
+        const int atom_raw = GE::atom_of(tile, n);
         const bool atom_ok = atom_raw < a.n_atoms;
         atom = atom_ok ? atom_raw : a.n_atoms - 1;
         ok = atom_ok && jraw >= 0;
         jn = ok ? jraw : atom;
         if (MLP == 0 && 4 * lane < APJ * H) {      // (first: whatever the address costs is paid before the long gathers are in flight)
-            const int qa = tile * APJ + (4 * lane) / H;
+            const int qa = GE::first_atom_of(tile) + (4 * lane) / H;
             int opq = 0;                             // (an offset the compiler cannot see through: the 64-bit lane address is formed
             asm volatile("" : "+v"(opq));            //  here, not hoisted out of the round loop and spilled)
-            qrow = qa < a.n_atoms ? ldg4(a.q + (size_t)tile * APJ * H + 4 * (lane + opq)) : float4{0.f, 0.f, 0.f, 0.f};
+            qrow = qa < a.n_atoms ? ldg4(a.q + (size_t)GE::first_atom_of(tile) * H + 4 * (lane + opq)) : float4{0.f, 0.f, 0.f, 0.f};
         }
         const float *pi = a.pre + (size_t)atom * a.ld_pre + 2 * H * MLP + 4 * g;
         const float *pj = a.pre + (size_t)jn * a.ld_pre + 2 * H * MLP + H + 4 * g;
@@ -293,10 +347,11 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
 #pragma unroll
             for (int k = 0; k < 3; ++k) { xi[k] = a.x[atom * 3 + k]; xj[k] = a.x[jn * 3 + k]; }
         }
-        wgt = a.ew[atom * KP + n % SEGW];
+        wgt = a.ew[atom * KP + GE::slot_of(tile, n)];
     };
 
     SM_TICK(a.stamps, 0);
+    if (!SM_SABL(4)) __builtin_amdgcn_s_setprio(3);      // the producers are the critical path of a round: their instructions go first
     if (tile_of(0) < wg_end) {             // the first unit's rows: the oldest memory operations of the wave
         const int j0 = peek(tile_of(0));
         if (tile_of(1) < wg_end) jraw_nx = peek(tile_of(1));
@@ -313,7 +368,8 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
         const int tile = tile_of(r);
         if (tile >= wg_end) return;
         const int slot = (r & 1) * TPR + my_slot;
-        const bool c_ok = ok;
+        if (r == 1) SM_TICK(a.stamps, 3);      // (diagnostic build: phases of the unit of round 1 -- 3 start, 4 rows summed, 5 first Linear,
+        const bool c_ok = ok;                  //  6 LayerNorm, 7 split + writes issued)
         const float c_wgt = wgt;
         const float4 c_q = qrow;
         if (fold) {      // coordinates from the table the prologue built
@@ -326,6 +382,18 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             acc[t] = f32x4{ga[t].x + gb[t].x, ga[t].y + gb[t].y, ga[t].z + gb[t].z, ga[t].w + gb[t].w};
+        if (r == 1) SM_TICK(a.stamps, 4);
+        auto request_next = [&]() {
+            if (tile_of(r + 1) < wg_end) {
+                const int jr = jraw_nx;
+                if (tile_of(r + 2) < wg_end) jraw_nx = peek(tile_of(r + 2));
+                request(tile_of(r + 1), jr);
+            }
+        };
+#if SM_STREAM_EARLY
+        // the rows have been consumed: request the next unit's at once (a whole unit of arithmetic plus the barrier to land in)
+        if constexpr (!(H2X && MLP == 1)) request_next();
+#endif
         // RBF block of the first Linear: one K = 32 step, six piece products per output tile
         {
             float cen[5], rb[5];
@@ -342,32 +410,34 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
                 const unsigned *ph = w1 + (0 * NT + t) * 192, *pm = w1 + (1 * NT + t) * 192, *pl = w1 + (2 * NT + t) * 192;
                 const u32x4 ah = {ph[0], ph[1], ph[2], 0u}, am = {pm[0], pm[1], pm[2], 0u}, al = {pl[0], pl[1], pl[2], 0u};
                 f32x4 c = acc[t];
+                if (!SM_SABL(1)) {
                 c = mfma_bf16(al, rh, c);      // smallest terms first
                 c = mfma_bf16(am, rm, c);
                 c = mfma_bf16(ah, rl, c);
                 c = mfma_bf16(am, rh, c);
                 c = mfma_bf16(ah, rm, c);
                 c = mfma_bf16(ah, rh, c);
+                } else c[0] += __builtin_bit_cast(float, al[0] ^ am[1] ^ ah[2]) * __builtin_bit_cast(float, rh[0] ^ rm[1] ^ rl[2]);
                 acc[t] = c;
+#if SM_STREAM_EARLY
+                if (t % 2 == 1) __builtin_amdgcn_sched_barrier(0);     // (the next rows are in flight in 64 registers: keep the scheduler
+#endif                                                                  //  from reading every fragment of the block ahead)
             }
         }
         // the rows have been consumed and the first Linear's fragments are dead: request the next unit's rows (they fly under
         // the LayerNorm, the split and the barrier; the h2x value producer, which still has a matrix product ahead and needs
         // the registers for it, requests them behind that product)
-        auto request_next = [&]() {
-            if (tile_of(r + 1) < wg_end) {
-                const int jr = jraw_nx;
-                if (tile_of(r + 2) < wg_end) jraw_nx = peek(tile_of(r + 2));
-                request(tile_of(r + 1), jr);
-            }
-        };
+        if (r == 1) SM_TICK(a.stamps, 5);
+#if !SM_STREAM_EARLY
         if constexpr (!(H2X && MLP == 1)) request_next();
+#endif
         float hid[NT * 4];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             hid[4 * t + 0] = acc[t][0]; hid[4 * t + 1] = acc[t][1]; hid[4 * t + 2] = acc[t][2]; hid[4 * t + 3] = acc[t][3];
         }
-        ln_relu_dlayout<NT>(hid, part + M::P_G, part + M::P_B, g);
+        if (!SM_SABL(2)) ln_relu_stream<NT>(hid, part + M::P_G, part + M::P_B, g);
+        if (r == 1) SM_TICK(a.stamps, 6);
         if constexpr (H2X && MLP == 1) {
             // h2x value MLP: the heads-wide second Linear here, from the LDS image; rows = heads, row 4 g + r in this lane
             const float4 bb = ldg4(part + M::P_B2 + 4 * g);
@@ -399,7 +469,9 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = hid[8 * b + j];
                 u32x4 xh, xm, xl;
-                split3_bf16(v, xh, xm, xl);
+                if (!SM_SABL(3)) split3_bf16(v, xh, xm, xl);
+                else { xh = u32x4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+                       xm = u32x4{__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])}; xl = xh; }
                 hb[(0 * NB + b) * 64] = xh; hb[(1 * NB + b) * 64] = xm; hb[(2 * NB + b) * 64] = xl;
             }
         }
@@ -407,6 +479,7 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
             if (4 * lane < APJ * H) *reinterpret_cast<float4 *>(lds + M::O_Q + slot * M::Q_TILE + 4 * lane) = c_q;
             if (g == 0) lds[M::O_W + slot * 16 + n] = c_ok ? c_wgt : -1.f;
         }
+        if (r == 1) SM_TICK(a.stamps, 7);
     };
 
     produce(0);
@@ -416,7 +489,6 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
         produce(r + 1);
         __syncthreads();
     }
-    SM_TICK(a.stamps, 3);
 }
 
 // ---- consumer wave t2 = G.wave ------------------------------------------------------------------------------------------------
@@ -428,9 +500,24 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
     const unsigned *ldsu = reinterpret_cast<const unsigned *>(lds);
     const int lane = G.lane, wave = G.wave, n = G.n, g = G.g, wg_first = G.wg_first, wg_end = G.wg_end, rounds = G.rounds;
     SM_TICK(a.stamps, 0);
+#if SM_STREAM_TOUCH
+    // Warm the L2 with the rows the producers will gather in the rounds after the first (the per-node products are tens of MB:
+    // a first touch comes from the Infinity Cache, 2-3 us away, and a producer has one round of look-ahead): the consumers
+    // have nothing to do until the first round is produced.  One load per 128-byte line, results discarded.
+    float touch = 0.f;
+    for (int tt = wg_first + TPR + wave; tt < wg_end; tt += GE::NCONS) {
+        const int ta = min(GE::atom_of(tt, n), a.n_atoms - 1);
+        const int tj = a.nbr[ta * KP + GE::slot_of(tt, n)];
+        const float *ra = a.pre + (size_t)ta * a.ld_pre + 32 * g, *rb = a.pre + (size_t)(tj >= 0 ? tj : ta) * a.ld_pre + H + 32 * g;
+        touch += ra[0] + rb[0] + ra[2 * H] + rb[2 * H];
+    }
+#endif
     int span0, span_n;
     stream_prologue<H, KP, H2X>(a, G, lds, span0, span_n);
     SM_TICK(a.stamps, 1);
+#if SM_STREAM_TOUCH
+    if (touch == 1.2345e-30f) a.out[0] = touch;      // (never true: keeps the loads)
+#endif
     // this wave's row block of the second Linears, in registers for the whole launch (loaded while the producers work on the
     // first round)
     u32x4 wk[3][NB], wv[3][NB];
@@ -463,8 +550,9 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
 #pragma unroll
             for (int b = 0; b < NB; ++b)
                 kbg = mfma_bf16x6(wk[0][b], wk[1][b], wk[2][b], hk[(0 * NB + b) * 64], hk[(1 * NB + b) * 64], hk[(2 * NB + b) * 64], ksm, kbg);
-            const int atom_raw = tile * APJ + n / SEGW;
+            const int atom_raw = GE::atom_of(tile, n);
             const bool atom_ok = atom_raw < a.n_atoms;
+            const int orow = GE::HALF ? tile : atom_raw;           // k > 16: every half-atom tile stores its own (tile-normalised) rows
             const float wc = lds[M::O_W + slot * 16 + n];
             const bool okc = wc >= 0.f;
             // logits of head 2 wave + (g >> 1): four of its dimensions in this lane group, four in the partner group g ^ 1.
@@ -478,6 +566,10 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
             const float ssum = seg_sum<SEGW>(e);
             const float alpha = ssum > 0.f ? e * __builtin_amdgcn_rcpf(ssum) : 0.f;
             const bool store = atom_ok && (n % SEGW) == 0;
+            if constexpr (GE::HALF) {        // this tile's softmax state of head 2 wave + (g >> 1), for the combine (online-softmax identity)
+                if (store && (g & 1) == 0)
+                    *reinterpret_cast<float2 *>(a.part_ms + ((size_t)tile * GE::HD + 2 * wave + (g >> 1)) * 2) = float2{mx, ssum};
+            }
             if constexpr (!H2X) {
                 const u32x4 *hv = hk + M::HID_MLP / 4;
                 f32x4 vsm = {0.f, 0.f, 0.f, 0.f}, vbg = {0.f, 0.f, 0.f, 0.f};
@@ -490,7 +582,7 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
                 float o[4];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) o[rr] = seg_sum<SEGW>(aw * (vbg[rr] + vsm[rr]));
-                if (store) stg4(a.out + (size_t)atom_raw * H + 16 * wave + 4 * g,
+                if (store) stg4(a.out + (size_t)orow * H + 16 * wave + 4 * g,
                                 float4{o[0] + sw * b2v.x, o[1] + sw * b2v.y, o[2] + sw * b2v.z, o[3] + sw * b2v.w});
             } else {
                 const float *vt = lds + M::O_VT + slot * M::VT_TILE;
@@ -500,14 +592,17 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
 #pragma unroll
                 for (int k = 0; k < 3; ++k) o[k] = seg_sum<SEGW>(av * vt[256 + 16 * k + n]);
                 if (store && (g & 1) == 0) {
-                    float *op = a.out + (size_t)atom_raw * 48 + stream_row_of_head<NT>(head) * 3;
+                    float *op = a.out + (size_t)orow * 48 + stream_row_of_head<NT>(head) * 3;
                     op[0] = o[0]; op[1] = o[1]; op[2] = o[2];
                 }
             }
         }
+        if (r == 0) SM_TICK(a.stamps, 3);      // (diagnostic build: this wave's work of rounds 0, 1, 2 done; 6: last barrier passed)
+        if (r == 1) SM_TICK(a.stamps, 4);
+        if (r == 2) SM_TICK(a.stamps, 5);
         __syncthreads();
     }
-    SM_TICK(a.stamps, 3);
+    SM_TICK(a.stamps, 6);
 }
 
 // One workgroup barrier per round; every role runs its own copy of the prologue, the loop and the barriers (a barrier counts
@@ -515,11 +610,11 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
 template <int H, int KP, bool H2X>
 __global__ void __launch_bounds__((H / 16 + kStreamProducers) * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 edge_stream_kernel(EdgeStreamArgs a) {
-    static_assert(KP == 8 || KP == 16, "one 16-slot tile per job (k <= 16)");
+    static_assert(KP == 8 || KP == 16 || KP == 32, "16-slot tiles");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const StreamGeo<H, KP, H2X> G(a);
     if (G.wave < G.NCONS) stream_consumer<H, KP, H2X>(a, G, lds);
     else if (((G.wave - G.NCONS) & 1) == 0) stream_producer<H, KP, H2X, 0>(a, G, lds, (G.wave - G.NCONS) >> 1);
     else stream_producer<H, KP, H2X, 1>(a, G, lds, (G.wave - G.NCONS) >> 1);
-    if constexpr (H2X) stream_vn_epilogue<H, KP>(a, G, lds);
+    if constexpr (H2X && KP <= 16) stream_vn_epilogue<H, KP>(a, G, lds);      // (k > 16: vn_stats / vn_apply follow the combine)
 }

@@ -67,6 +67,10 @@ def _check_device_tensor(name, t, dtype):
     return t.contiguous()
 
 
+# library defaults of the options the precision modes touch (shapemol_set_option; include/shapemol_hip.h)
+DEFAULT_OPTIONS = {"edge_bf16": 2, "node_f16": 0, "feat_f16": 0}
+
+
 class ScorePosNet3D(nn.Module):
     _accelerated = True      # shapemol_amd.sampling: this sample_diffusion takes the private host-buffer keyword
 
@@ -157,8 +161,16 @@ class ScorePosNet3D(nn.Module):
         mean, var = self._bn_running()
         _lib.check(lib.shapemol_set_bn_running(ctx, mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p), mean.size),
                    "shapemol_set_bn_running")
-        for name, value in self.__dict__.get("_options", {}).items():       # options set through set_option apply to every context
-            _lib.check(lib.shapemol_set_option(ctx, name.encode(), int(value)), "shapemol_set_option")
+        # options set through set_option apply to every context; replayed in a dependency-safe order (feat_f16 needs the f16
+        # kernels selected first), and a context that cannot take them is destroyed, not leaked
+        opts = self.__dict__.get("_options", {})
+        order = sorted(opts, key=lambda k: {"edge_bf16": 0, "node_f16": 1, "feat_f16": 3}.get(k, 2))
+        try:
+            for name in order:
+                _lib.check(lib.shapemol_set_option(ctx, name.encode(), int(opts[name])), "shapemol_set_option")
+        except Exception:
+            lib.shapemol_destroy(ctx)
+            raise
         return ctx
 
     def _sync_bn_mode(self, ctx, slot=0):
@@ -203,6 +215,25 @@ class ScorePosNet3D(nn.Module):
             _lib.check(_lib.load().shapemol_set_option(ent["ctx"], name.encode(), int(value)), "shapemol_set_option")
             if name == "bn_eval":
                 ent["bn_eval"] = bool(value)
+
+    def set_knn_pins(self, step=None, atom=None, nbr=None, num_steps=None):
+        """Diagnostic of the parity tests (shapemol_set_knn_pins): pin the kNN graph of the following sample_diffusion calls at
+        the given (reverse step, atom) pairs to the given neighbour lists; no arguments remove the pins."""
+        dev = next(self.parameters()).device
+        ctx = self._context(dev)
+        lib = _lib.load()
+        if step is None or len(step) == 0:
+            _lib.check(lib.shapemol_set_knn_pins(ctx, None, 0, None, None, 0, 0), "shapemol_set_knn_pins")
+            return
+        step = np.asarray(step, np.int64)
+        order = np.argsort(step, kind="stable")
+        step, atom, nbr = step[order], np.ascontiguousarray(np.asarray(atom, np.int32)[order]), np.ascontiguousarray(np.asarray(nbr, np.int32)[order])
+        n_steps = int(num_steps if num_steps is not None else self.num_timesteps)
+        off = np.zeros(n_steps + 1, np.int32)
+        np.add.at(off, step + 1, 1)
+        off = np.ascontiguousarray(np.cumsum(off).astype(np.int32))
+        _lib.check(lib.shapemol_set_knn_pins(ctx, off.ctypes.data_as(C.c_void_p), n_steps, atom.ctypes.data_as(C.c_void_p),
+                                             nbr.ctypes.data_as(C.c_void_p), len(atom), nbr.shape[1]), "shapemol_set_knn_pins")
 
     def debug_read(self, name, shape, dtype):
         out = np.empty(shape, dtype=dtype)

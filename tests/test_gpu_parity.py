@@ -14,6 +14,43 @@ DEV = "cuda:0"
 FWD_TOL = 2e-5      # one forward, float32, values up to ~4
 POS_TOL = 1e-4      # BASELINE.json north_star: coordinates within 1e-4 abs, atom types exact
 
+# Precision modes of the matrix products (shapemol_set_option): "exact" = every operand split exactly into three bf16 pieces (the 24
+# significand bits of fp32), six products, streaming edge kernels -- the library's default and the path the bench's headline runs
+# on; "f16x2" = two f16 pieces (22-23 bits), three products (the round-2/3 kernels; an optional faster mode).
+MODES = {"exact": {"edge_bf16": 2, "node_f16": 0}, "f16x2": {"edge_bf16": 3, "node_f16": 1}}
+MODE_IDS = list(MODES)
+
+
+def set_mode(m, mode):
+    for k in ("edge_bf16", "node_f16"):
+        m.set_option(k, MODES[mode][k])
+    return m
+
+
+def hip(mode, **kw):
+    """The cached HIP model with a precision mode selected (restored to the defaults after the test by _restore_modes)."""
+    return set_mode(hip_model(**kw), mode)
+
+
+@pytest.fixture(params=MODE_IDS)
+def mode(request):
+    return request.param
+
+
+@pytest.fixture(autouse=True)
+def _restore_modes():
+    """Every test starts from the library defaults on every cached model, whatever the previous test selected."""
+    yield
+    import util
+    from shapemol_amd.molopt_score_model import DEFAULT_OPTIONS
+    for key, m in list(util._cache.items()):
+        if key[0] != "h":
+            continue
+        opts = m.__dict__.get("_options", {})
+        for k in ("feat_f16", "node_f16", "edge_bf16"):
+            if k in opts and opts[k] != DEFAULT_OPTIONS[k]:
+                m.set_option(k, DEFAULT_OPTIONS[k])
+
 
 def run_forward(m, f, tkey, pos="pos", v="v"):
     with torch.no_grad():
@@ -22,7 +59,7 @@ def run_forward(m, f, tkey, pos="pos", v="v"):
 
 def test_library_loaded_and_device():
     from shapemol_amd import _lib
-    assert _lib.load().shapemol_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().shapemol_abi_version() == _lib.ABI_VERSION == 5
     assert torch.cuda.is_available()
 
 
@@ -46,9 +83,9 @@ def test_graph_stage_neighbours_and_edge_weights():
 
 
 @pytest.mark.parametrize("nl", [1, 2, 4, 8])
-def test_layer_taps(nl):
+def test_layer_taps(nl, mode):
     """h and x after the first `nl` layers against the reference's per-layer hooks."""
-    m = hip_model()
+    m = hip(mode)
     f = golden("forward_b4.npz")
     m.set_option("stop_layer", nl)
     try:
@@ -63,17 +100,19 @@ def test_layer_taps(nl):
 
 
 @pytest.mark.parametrize("name", ["t999", "t500", "t0", "tmix"])
-def test_forward_b4_golden(name):
-    m = hip_model()
+def test_forward_b4_golden(name, mode):
+    m = hip(mode)
     f = golden("forward_b4.npz")
     out = run_forward(m, f, name + "_t")
     for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
         assert maxabs(out[k], f[f"{name}_{k}"]) < FWD_TOL, k
 
 
-@pytest.mark.parametrize("opts", [{"edge_bf16": 0}, {"edge_bf16": 1}, {"lin_bf16": 0, "chain_bf16": 0}, {"node_f16": 0},
-                                  {"edge_bf16": 1, "node_f16": 0}, {"vn_fuse": 1}, {"vn_fuse": 0}],
-                         ids=["edge_fp32", "edge_bf16x6", "node_fp32", "node_bf16x6", "all_exact_bf16x6", "vn_grid_barrier", "vn_separate"])
+@pytest.mark.parametrize("opts", [{"edge_bf16": 0}, {"edge_bf16": 1}, {"lin_bf16": 0, "chain_bf16": 0}, {"edge_bf16": 3, "node_f16": 0},
+                                  {"edge_bf16": 1, "node_f16": 0}, {"vn_fuse": 1}, {"vn_fuse": 0}, {"edge_bf16": 2, "node_f16": 1},
+                                  {"edge_bf16": 3, "node_f16": 1, "vn_fuse": 1}, {"edge_bf16": 3, "node_f16": 1, "vn_fuse": 0}],
+                         ids=["edge_fp32", "edge_bf16x6_phase", "node_fp32", "edge_f16x2_node_bf16x6", "all_exact_phase", "vn_grid_barrier", "vn_separate",
+                              "edge_stream_node_f16x2", "f16x2_vn_grid_barrier", "f16x2_vn_separate"])
 def test_forward_alternative_kernels_golden(opts):
     """The optional kernel variants behind shapemol_set_option compute the same forward (ragged batch too)."""
     m = hip_model()
@@ -91,12 +130,13 @@ def test_forward_alternative_kernels_golden(opts):
         assert int(m.debug_read("vn_err", (1,), np.int32)[0]) == 0
     finally:
         for k in opts:
-            m.set_option(k, {"edge_bf16": 3, "lin_bf16": 1, "chain_bf16": 1, "vn_fuse": 2, "node_f16": 1}[k])
+            if k not in ("edge_bf16", "node_f16"):      # (those two are restored by _restore_modes)
+                m.set_option(k, {"lin_bf16": 1, "chain_bf16": 1, "vn_fuse": 2}[k])
 
 
-def test_forward_ragged_golden():
+def test_forward_ragged_golden(mode):
     """1-, 2-, 5-atom molecules: fewer than k neighbours / none at all."""
-    m = hip_model()
+    m = hip(mode)
     f = golden("forward_ragged.npz")
     out = run_forward(m, f, "t")
     for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
@@ -104,21 +144,21 @@ def test_forward_ragged_golden():
 
 
 @pytest.mark.parametrize("tag", ["small", "k32"])
-def test_forward_variants_golden(tag):
+def test_forward_variants_golden(tag, mode):
     """reduced-width model (H=32, 4 heads, 2 layers) and the k=32 / 40-80 atom stress variant."""
     f = golden(f"forward_{tag}.npz")
     ov = json.loads(str(f["overrides"]))
-    m = hip_model(seed=9, **ov)
+    m = hip(mode, seed=9, **ov)
     out = run_forward(m, f, "t", pos="init_pos", v="init_v")
     for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
         assert maxabs(out[k], f[k]) < FWD_TOL, k
 
 
 @pytest.mark.parametrize("k", [4, 12, 16])
-def test_forward_other_k_vs_oracle(k):
+def test_forward_other_k_vs_oracle(k, mode):
     """Neighbour counts other than the configured 8: k = 4 (half-empty 8-slot tiles), k = 12 and 16 (the 16-slot,
     one-atom-per-job instantiation of the edge kernels), with molecules both smaller and larger than k + 1."""
-    m = hip_model(seed=5, knn=k)
+    m = hip(mode, seed=5, knn=k)
     sd, dm, _, _ = oracle_model(seed=5, knn=k)
     bb = synth.synthetic_batch(12, seed=77, atoms_range=(6, 30))
     t = (synth.hash_u24(12, 3, 3) % 1000).astype(np.int64)
@@ -130,10 +170,10 @@ def test_forward_other_k_vs_oracle(k):
 
 
 @pytest.mark.parametrize("nmol,rng", [(1, (17, 17)), (1, (1, 1)), (3, (33, 48))], ids=["one_molecule", "one_atom", "large_molecules"])
-def test_forward_extreme_batches_vs_oracle(nmol, rng):
+def test_forward_extreme_batches_vs_oracle(nmol, rng, mode):
     """A batch of a single molecule, of a single atom (no edges at all; batch-norm over one sample), and molecules larger
     than anything in the MOSES prior."""
-    m = hip_model()
+    m = hip(mode)
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(nmol, seed=31, atoms_range=rng)
     t = np.full(nmol, 321, np.int64)
@@ -144,9 +184,9 @@ def test_forward_extreme_batches_vs_oracle(nmol, rng):
         assert maxabs(out[key], ref[key]) < FWD_TOL, key
 
 
-def test_forward_b256_vs_oracle():
+def test_forward_b256_vs_oracle(mode):
     """BASELINE config-2 size (256 molecules, ~5.5k atoms) against the CPU oracle, one evaluation."""
-    m = hip_model()
+    m = hip(mode)
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(256, seed=2021)
     t = (synth.hash_u24(256, 9, 9) % 1000).astype(np.int64)
@@ -173,10 +213,10 @@ def _chain(m, init_pos, init_v, batch, shape, steps, eps, u, **kw):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_chain_b4_s50_golden(use_graph):
+def test_chain_b4_s50_golden(use_graph, mode):
     """BASELINE config 1 analogue with the reference's own torch-RNG draws replayed: atom types
     integer-exact at every step, coordinates within 1e-4."""
-    m = hip_model()
+    m = hip(mode)
     c = golden("chain_b4_s50_torchrng.npz")
     r = _chain(m, c["init_pos"], c["init_v"], c["batch"], c["shape"], 50, c["eps"], c["u"], use_graph=use_graph)
     assert np.array_equal(r["v"].cpu().numpy(), c["v"])
@@ -201,9 +241,9 @@ def test_init_v_sampling_matches_reference_draw():
 
 
 @pytest.mark.parametrize("tag", ["b16_s100", "b4_s1000"])
-def test_chain_hash_noise_golden(tag):
+def test_chain_hash_noise_golden(tag, mode):
     """Full 1000-step chain (B=4) and a 100-step B=16 chain against the reference's end state."""
-    m = hip_model()
+    m = hip(mode)
     c = golden(f"chain_{tag}_hash.npz")
     B, S, seed, every = int(c["B"]), int(c["S"]), int(c["seed"]), int(c["every"])
     bb = synth.synthetic_batch(B, seed=seed)
@@ -215,9 +255,9 @@ def test_chain_hash_noise_golden(tag):
     assert maxabs(torch.stack(r["pos_traj"][::every]), c["pos_traj_sub"]) < POS_TOL
 
 
-def test_chain_b256_vs_oracle_30_steps():
+def test_chain_b256_vs_oracle_30_steps(mode):
     """Headline batch size: 256 molecules, first 30 reverse steps, against the CPU oracle."""
-    m = hip_model()
+    m = hip(mode)
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(256, seed=2021)
     n, S = len(bb["batch"]), 30
@@ -387,33 +427,55 @@ def _golden_chain(m, c, atoms_range=None, max_atoms=None):
     return errs
 
 
-def test_chain_b256_s1000_golden():
+def test_chain_b256_s1000_golden(mode):
     """BASELINE configs[1] at full length, free-running: 256 molecules x 1000 reverse steps (graph replay) against the
     REFERENCE's own run on the same noise.  Atom types must be exact at every snapshot and at the end; coordinates must
     agree within 1e-4 for every atom until the first kNN near-tie flips a neighbour (measured: after step 200; see
     test_chain_b256_s1000_windows_golden for why the free-running tail cannot be held to 1e-4 by ANY second float32
     implementation, and for the gate that covers all 1000 steps).  The tail is recorded, and bounded loosely."""
     from util import record
-    errs = _golden_chain(hip_model(), golden("chain_b256_s1000_hash.npz"), max_atoms=38)
-    record("chain_b256_s1000_golden", **errs)
+    errs = _golden_chain(hip(mode), golden("chain_b256_s1000_hash.npz"), max_atoms=38)
+    record("chain_b256_s1000_golden", mode=mode, **errs)
     assert errs["v_mismatch_end"] == 0 and errs["v_mismatch_snapshots"] == 0, errs
     assert errs["pos_head"] < POS_TOL and errs["pos_first_200"] < POS_TOL, errs
     assert errs["pos_end_median_mol"] < 5e-4, errs           # the bulk of the molecules stays on the reference's trajectory
 
 
-def test_chain_b1024_s50_golden():
+def test_chain_b256_s1000_free_run_pinned_golden(mode):
+    """The literal north-star gate: BASELINE configs[1], 256 molecules x 1000 reverse steps FREE-RUNNING from the initial state
+    (one call, graph replay, the reference's noise), every molecule within 1e-4 of the reference at every 50th step and at the
+    end, atom types exact throughout -- with the kNN choice pinned to the reference's wherever the reference's own k-th /
+    (k+1)-th candidates are closer than a relative 5e-4 in squared distance (tests/golden/chain_b256_s1000_pins.npz, recorded
+    by the reference run itself: 24.5k of the 5.5M (step, atom) pairs, 0.44 %).  Those are the only discontinuities of the
+    path: a second float32 implementation picks the other candidate there and follows another trajectory for good
+    (test_chain_b256_s1000_golden records that lottery, the windowed test bounds it).  With them pinned the chain stays on the
+    reference's trajectory, i.e. everything the kernels compute is continuous-error-only over the full length."""
+    from util import record
+    m = hip(mode)
+    c, pins = golden("chain_b256_s1000_hash.npz"), golden("chain_b256_s1000_pins.npz")
+    m.set_knn_pins(pins["step"], pins["atom"], pins["nbr"])
+    try:
+        errs = _golden_chain(m, c, max_atoms=38)
+    finally:
+        m.set_knn_pins()
+    record("chain_b256_s1000_free_run_pinned_golden", mode=mode, pins=int(len(pins["step"])), **errs)
+    assert errs["v_mismatch_end"] == 0 and errs["v_mismatch_snapshots"] == 0, errs
+    assert errs["pos_snapshots"] < POS_TOL and errs["pos_end"] < POS_TOL and errs["mols_over_1e-4_end"] == 0, errs
+
+
+def test_chain_b1024_s50_golden(mode):
     """BASELINE configs[2] batch size (1024 molecules, <= 38 atoms): 50 reverse steps against the reference."""
     from util import record
-    errs = _golden_chain(hip_model(), golden("chain_b1024_s50_hash.npz"), max_atoms=38)
-    record("chain_b1024_s50_golden", **errs)
+    errs = _golden_chain(hip(mode), golden("chain_b1024_s50_hash.npz"), max_atoms=38)
+    record("chain_b1024_s50_golden", mode=mode, **errs)
     assert errs["v_mismatch_end"] == 0 and errs["v_mismatch_snapshots"] == 0, errs
     assert errs["pos_end"] < POS_TOL and errs["pos_snapshots"] < POS_TOL, errs
 
 
-def test_forward_b1024_vs_oracle():
+def test_forward_b1024_vs_oracle(mode):
     """B = 1024 (~22k atoms): the multi-job instantiation of the edge kernels at its natural size."""
     from util import record
-    m = hip_model()
+    m = hip(mode)
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(1024, seed=14, max_atoms=38)
     t = (synth.hash_u24(1024, 9, 14) % 1000).astype(np.int64)
@@ -421,7 +483,7 @@ def test_forward_b1024_vs_oracle():
     with torch.no_grad():
         out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
     errs = {k: maxabs(out[k], ref[k]) for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v")}
-    record("forward_b1024_vs_oracle", n_atoms=len(bb["batch"]), **errs)
+    record("forward_b1024_vs_oracle", mode=mode, n_atoms=len(bb["batch"]), **errs)
     assert max(errs.values()) < FWD_TOL, errs
 
 
@@ -489,13 +551,13 @@ def test_new_seed_and_buffers_replay_the_captured_graph():
     assert torch.equal(r2["v"], r2b["v"]) and maxabs(r2["pos"], r2b["pos"]) < 1e-6
 
 
-def _windows_gate(name, c, tail, max_flagged):
+def _windows_gate(name, c, tail, max_flagged, mode):
     """A full-length chain in windows, each started from the REFERENCE's state at the window's first step and compared with
     the reference's state at its last: 50-step windows from the every-50th snapshots, and 10-step windows over the last 50
     steps (`tail` = (first_step, every, pos, v): the reference's states after reverse steps first_step, first_step + every,
     ...), where the posterior hands the network's x0 estimate through almost unchanged.  Returns the record."""
     from tools_knn import knn_margin_rel
-    m = hip_model()
+    m = hip(mode)
     B, S, seed, every = int(c["B"]), int(c["S"]), int(c["seed"]), int(c["every"])
     bb = synth.synthetic_batch(B, seed=seed, max_atoms=38)
     assert np.array_equal(bb["counts"], c["counts"])
@@ -531,7 +593,7 @@ def _windows_gate(name, c, tail, max_flagged):
             med_last.append(dict(first_step=s0, steps=ns, median=float(np.median(mol_err)), max_unflagged=float(clean.max()) if len(clean) else 0.0))
     rec = dict(windows=len(marks) - 1, worst_unflagged=worst_clean, atom_type_mismatches=v_bad, flagged=flagged, last_windows=med_last)
     from util import record
-    record(name, **rec)
+    record(name, mode=mode, **rec)
     assert v_bad == 0, rec
     assert worst_clean < POS_TOL, rec
     # measured (profiles/r02_final, r03): 4 flagged molecules in 1000 steps at B = 256, every one with a neighbour near-tie of
@@ -541,7 +603,7 @@ def _windows_gate(name, c, tail, max_flagged):
     return rec
 
 
-def test_chain_b256_s1000_windows_golden():
+def test_chain_b256_s1000_windows_golden(mode):
     """The full 1000 steps at B = 256 (BASELINE configs[1]) in windows: twenty 50-step windows and, over the last 50 steps,
     five of ~10, each started from the REFERENCE's state and compared with the reference's state at the window's end.
 
@@ -554,10 +616,10 @@ def test_chain_b256_s1000_windows_golden():
     own window and molecule, which the test then has to justify one by one: a molecule may exceed 1e-4 only if a neighbour
     near-tie (relative margin < 2e-6) occurred on its way."""
     c, ct = golden("chain_b256_s1000_hash.npz"), golden("chain_b256_s1000_tail_hash.npz")
-    _windows_gate("chain_b256_s1000_windows_golden", c, (int(ct["first_step"]), int(ct["every"]), ct["pos_traj_tail"], ct["v_traj_tail"]), max_flagged=8)
+    _windows_gate("chain_b256_s1000_windows_golden", c, (int(ct["first_step"]), int(ct["every"]), ct["pos_traj_tail"], ct["v_traj_tail"]), max_flagged=8, mode=mode)
 
 
-def test_chain_b1024_s1000_windows_golden():
+def test_chain_b1024_s1000_windows_golden(mode):
     """BASELINE configs[2] / the per-GPU share of configs[3] at full length: 1024 molecules (21.9k atoms) x 1000 reverse
     steps against the reference's own run, in the same windows (sliced edge launches, separate node stage)."""
     import os
@@ -566,7 +628,7 @@ def test_chain_b1024_s1000_windows_golden():
         pytest.skip("fixture chain_b1024_s1000_hash.npz not generated (tests/golden/make_golden_r2.py b1024_s1000, ~3 CPU-hours)")
     c = golden("chain_b1024_s1000_hash.npz")
     _windows_gate("chain_b1024_s1000_windows_golden", c, (int(c["tail_first"]), int(c["tail_every"]), c["pos_traj_tail"], c["v_traj_tail"]),
-                  max_flagged=32)
+                  max_flagged=32, mode=mode)
 
 
 def test_sampling_driver_reproduces_reference_from_seeds():
@@ -599,26 +661,26 @@ def test_sampling_driver_reproduces_reference_from_seeds():
     assert maxabs(np.concatenate([x[-1] for x in vt_traj]), c["vt_last"]) < POS_TOL
 
 
-def test_forward_k32_b64_golden():
+def test_forward_k32_b64_golden(mode):
     """BASELINE configs[4] analogue: 64 molecules of 40-80 atoms, k = 32, full depth, against the reference."""
     from util import record
     f = golden("forward_k32_b64.npz")
-    m = hip_model(seed=9, knn=32)
+    m = hip(mode, seed=9, knn=32)
     bb = synth.synthetic_batch(64, seed=35, atoms_range=(40, 80))
     assert np.array_equal(bb["counts"], f["counts"])
     with torch.no_grad():
         out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(f["t"], DEV))
     errs = {k: maxabs(out[k], f[k]) for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v")}
-    record("forward_k32_b64_golden", n_atoms=len(bb["batch"]), **errs)
+    record("forward_k32_b64_golden", mode=mode, n_atoms=len(bb["batch"]), **errs)
     assert max(errs.values()) < FWD_TOL, errs
 
 
-def test_forward_k32_b512_vs_oracle():
+def test_forward_k32_b512_vs_oracle(mode):
     """BASELINE configs[4] at its per-GPU size: 512 molecules of 40-80 atoms (30.9k atoms, 989k edge slots), k = 32, full
     depth, one evaluation against the CPU oracle (itself pinned at k = 32 by forward_k32_b64.npz / chain_k32_b64_s20);
     neighbour lists integer-exact."""
     from util import record
-    m = hip_model(seed=9, knn=32)
+    m = hip(mode, seed=9, knn=32)
     sd, dm, _, _ = oracle_model(seed=9, knn=32)
     B = 512
     bb = synth.synthetic_batch(B, seed=4096, atoms_range=(40, 80))
@@ -633,15 +695,15 @@ def test_forward_k32_b512_vs_oracle():
     ref_sets = np.sort(src.numpy().reshape(n, 32), 1) if len(src) == n * 32 else None
     if ref_sets is not None:         # every molecule has >= 40 atoms: all 32 slots are filled
         assert np.array_equal(np.sort(nbr, 1), ref_sets)
-    record("forward_k32_b512_vs_oracle", n_atoms=n, **errs)
+    record("forward_k32_b512_vs_oracle", mode=mode, n_atoms=n, **errs)
     assert max(errs.values()) < FWD_TOL, errs
 
 
-def test_chain_k32_b64_s20_golden():
+def test_chain_k32_b64_s20_golden(mode):
     """The same configuration over 20 reverse steps against the reference: atom types exact, coordinates within 1e-4."""
     from util import record
-    errs = _golden_chain(hip_model(seed=9, knn=32), golden("chain_k32_b64_s20_hash.npz"), atoms_range=(40, 80))
-    record("chain_k32_b64_s20_golden", **errs)
+    errs = _golden_chain(hip(mode, seed=9, knn=32), golden("chain_k32_b64_s20_hash.npz"), atoms_range=(40, 80))
+    record("chain_k32_b64_s20_golden", mode=mode, **errs)
     assert errs["v_mismatch_end"] == 0 and errs["v_mismatch_snapshots"] == 0, errs
     assert errs["pos_end"] < POS_TOL and errs["pos_snapshots"] < POS_TOL, errs
 
@@ -650,7 +712,7 @@ def test_chain_k32_b64_s20_golden():
 def test_forward_b1024_edge_tile_variants(tiles):
     """The multi-job forms of the f16 edge kernels at B = 1024: the looping launch (eight waves per workgroup; the default, -1 =
     automatic) and sliced launches of the one-job kernel."""
-    m = hip_model()
+    m = hip("f16x2")
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(1024, seed=14, max_atoms=38)
     t = (synth.hash_u24(1024, 9, 14) % 1000).astype(np.int64)
@@ -670,7 +732,7 @@ def test_chain_b1024_looping_edge_kernels_equal_sliced_launches():
     per workgroup, next job's rows prefetched; the coordinate update folded into the next x2h kernel over the workgroup's
     molecule span) against the sliced one-job launches: same jobs, same arithmetic -- only the order of the float64
     batch-norm atomics differs."""
-    m = hip_model()
+    m = hip("f16x2")
     B, S = 1024, 6
     bb = synth.synthetic_batch(B, seed=14, max_atoms=38)
     eps, u = hash_noise(len(bb["batch"]), S, 14)
@@ -850,6 +912,8 @@ def test_fp16_range_guard_of_the_node_kernels():
     m = shapemol_amd.ScorePosNet3D(cfg, 15)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=True)
     m = m.to(DEV)
+    m.set_option("edge_bf16", 3)
+    m.set_option("node_f16", 1)      # (the two-piece f16 kernels; the default exactly split bf16 kernels have no range limit)
     bb = synth.synthetic_batch(4, seed=3)
     args = (T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(np.full(4, 10, np.int64), DEV))
     with torch.no_grad():
@@ -868,7 +932,7 @@ def test_fused_launches_equal_separate_launches():
     x2h_chain16_kernel) run the same arithmetic in the same order as the kernels they replace: a chain with them is
     bit-identical to a chain without; the last layer's coordinate update inside the DDPM kernel equals the separate launch
     to rounding."""
-    m = hip_model()
+    m = hip("f16x2")
     for B, seed, rng in ((48, 9, None), (10, 4, (40, 80))):      # MOSES-size molecules; larger ones (two candidate chunks per lane)
         bb = synth.synthetic_batch(B, seed=seed, atoms_range=rng)
         eps, u = hash_noise(len(bb["batch"]), 6, seed)
@@ -887,11 +951,11 @@ def test_fused_launches_equal_separate_launches():
             assert torch.equal(torch.stack(r1["pos_traj"]), torch.stack(r0["pos_traj"])), opt
 
 
-def test_folded_coordinate_update_equals_separate_launch():
+def test_folded_coordinate_update_equals_separate_launch(mode):
     """The coordinate update of a layer folded into the next x2h kernel (chains, default) against the separate vn_apply
     launches: same chain to rounding; and a max_mol_atoms hint below the truth is reported, not silently wrong."""
     from shapemol_amd import _lib
-    m = hip_model()
+    m = hip(mode)
     bb = synth.synthetic_batch(48, seed=9)
     eps, u = hash_noise(len(bb["batch"]), 12, 9)
     r1 = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], 12, eps, u)
@@ -1045,7 +1109,7 @@ def test_f16_features_mode_is_a_bounded_approximation():
     where the default is within 2e-5, the same atom-type argmax for > 99 % of the atoms, a clean status, and the default
     path bit-identical again after switching back."""
     from util import record
-    m = hip_model()
+    m = hip("f16x2")
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(256, seed=2021)
     t = (synth.hash_u24(256, 9, 9) % 1000).astype(np.int64)
@@ -1380,12 +1444,12 @@ def test_sharded_sampling_job_two_ranks_equals_one():
             assert np.array_equal(a_, b_)
 
 
-def test_forward_and_chain_b4096_vs_oracle():
+def test_forward_and_chain_b4096_vs_oracle(mode):
     """Four times the largest BASELINE batch on one GPU (4096 MOSES-sized molecules, 88 k atoms, 0.7 M edges: 64-bit offsets,
     grids of thousands of workgroups, looping edge launches with ~340 jobs per workgroup): one evaluation and one chain step
     against the CPU oracle (the oracle's two evaluations at this size are ~90 s of the test)."""
     from util import record
-    m = hip_model()
+    m = hip(mode)
     sd, dm, _, _ = oracle_model()
     B = 4096
     bb = synth.synthetic_batch(B, seed=4097, max_atoms=38)
@@ -1400,6 +1464,6 @@ def test_forward_and_chain_b4096_vs_oracle():
     r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
     ro = O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S, lambda s_: (eps[s_], u[s_]), keep_traj=False)
     errs["chain_pos"] = maxabs(r["pos"], ro["pos"])
-    record("forward_and_chain_b4096_vs_oracle", n_atoms=n, **errs)
+    record("forward_and_chain_b4096_vs_oracle", mode=mode, n_atoms=n, **errs)
     assert np.array_equal(r["v"].cpu().numpy(), ro["v"].numpy())
     assert max(errs.values()) < FWD_TOL, errs

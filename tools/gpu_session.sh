@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+rm -f gpurun_out/parity_errors.jsonl
+timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider --durations=15 > gpurun_out/gpu_tests.log 2>&1; echo "rc=$?" >> gpurun_out/gpu_tests.log; tail -45 gpurun_out/gpu_tests.log | cut -c1-250
