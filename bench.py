@@ -44,12 +44,15 @@ TRAIN_YML = os.path.join(ROOT, "config", "training",
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0      # dense f16 / bf16 matrix peak (same guide)
 HBM_PEAK_GBS = 8000.0              # HBM3E peak (same guide)
-PROFILE_DIR = "r03"          # profiles/<dir>/pmc_traffic*.json hold the PMC traffic of the kernels timed here
+PROFILE_DIR = "r04"          # profiles/<dir>/pmc_traffic*.json hold the PMC traffic of the kernels timed here
 CHAIN_STEPS = 1000                 # the metric is quoted for 1000-step chains
-# what the arithmetic is: fp32 inputs, outputs, accumulators and vector work; the matrix products take their fp32 operands as
-# two f16 pieces each (hi + lo, 22 significand bits) and sum three piece products in fp32.  `exact_mode` on the JSON line times
-# the same chain with every operand split exactly (three bf16 pieces, six products: fp32-exact products).
-DTYPE = "f32 (matrix operands as 2 x f16 pieces = 22 bits, fp32 accumulate)"
+# what the arithmetic is: fp32 inputs, outputs, accumulators and vector work; every matrix operand is split EXACTLY into three
+# bf16 pieces (8 + 8 + 8 = the 24 significand bits of fp32, full fp32 exponent range) and a product is the six piece products of
+# total order <= 2 with fp32 accumulation: the dropped terms are below 2^-24 |x w|.  This is the library's default mode and what
+# `value` is measured on; `f16x2_mode` on the JSON line times the same chain with two-piece f16 operands (22-23 bits, three
+# products: the round-2/3 kernels), `f16_features_mode` with single f16 pieces (11 bits) -- optional modes, never `value`.
+DTYPE = "f32 (matrix operands split exactly into 3 x bf16 pieces = 24 bits, six piece products, fp32 accumulate)"
+PIECE_PRODUCTS = 6                 # matrix instructions per fp32 product in the headline mode
 
 
 def executed_flops_per_atom_step(H, L, k, G=20, heads=16, C=15, S=32):
@@ -87,6 +90,16 @@ def cpu_baseline(cfg, batch, n_steps, threads=0):
     return dt, torch.get_num_threads()
 
 
+def lib_sha16():
+    """First 16 hex digits of the SHA-1 of the loaded library: PMC summaries are keyed to the build they were measured on."""
+    import hashlib
+    from shapemol_amd import _lib
+    try:
+        return hashlib.sha1(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -108,8 +121,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--cpu-steps", type=int, default=20, help="reverse steps of the CPU oracle to time (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU oracle (0 = the measured best, see CPU_THREADS_DEFAULT)")
-    ap.add_argument("--exact-steps", type=int, default=-1, help="reverse steps of the exact-operand chain (extra field `exact_mode`; "
-                                                                "-1 = as --steps, 0 = skip)")
+    ap.add_argument("--exact-steps", "--mode-steps", dest="exact_steps", type=int, default=-1,
+                    help="reverse steps of the optional-mode chains (extra fields `f16x2_mode`, `f16_features_mode`; -1 = as --steps, 0 = skip)")
     ap.add_argument("--no-traj", action="store_true", help="do not keep per-step trajectories")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--concurrent", type=int, default=2,
@@ -231,13 +244,15 @@ def main():
         "config": {"workload": (("BASELINE configs[1]: batch 256" if args.batch == 256 else
                                  ("BASELINE configs[2]/[3] size: batch 1024" if args.batch == 1024 else f"batch {args.batch}")) +
                                 (f" molecules of {atoms_range[0]}-{atoms_range[1]} atoms" if atoms_range else " MOSES-prior molecules (9-27 atoms)") +
-                                f" per GPU, 1000-step chain, fp32 results, k={cfg['knn']}, synthetic shapes + hash-filled weights"),
+                                f" per GPU, 1000-step chain, fp32 results, k={cfg['knn']}, synthetic shapes + hash-filled weights" +
+                                (f"; besides the {warm} warm-up steps an untimed {clock_warm}-step chain runs first to reach the loaded clocks" if clock_warm else "")),
                    "batch_per_gpu": args.batch, "atoms_per_gpu": n_atoms, "total_atoms": total_atoms,
                    "noise": "device Philox", "trajectories": "kept in HBM" if not args.no_traj else "off",
                    "launch": "hipGraph replay" if use_graph else "eager", "parallelism": f"dp{world} (whole batches per rank)",
                    "ranks_seen": (dist.get_world_size() if dist is not None else 1), **({"collective": f"forced 1-rank {args.backend} gather"} if (dist is not None and world == 1) else {}), "ms_per_step_by_rank": rank_ms, **({"options": args.opt} if args.opt else {}),
-                   "matrix_products": "edge and node MLPs: two-piece f16 operands (22 significand bits), three products per term, fp32 "
-                                      "accumulate; everything else fp32 (options edge_bf16 = 1, node_f16 = 0: exactly split bf16 operands)"},
+                   "matrix_products": "edge and node MLPs: every operand split exactly into three bf16 pieces (24 significand bits), six "
+                                      "products per term on v_mfma_f32_16x16x32_bf16, fp32 accumulate; everything else fp32 (library defaults "
+                                      "edge_bf16 = 2, node_f16 = 0)"},
     }
 
     log(f"timed region done: {elapsed:.3f} s, {value:.2f} molecules/s")
@@ -261,46 +276,46 @@ def main():
         slices = max(1.0, dom_n / (8.0 * max(1, args.profile_steps)))
         flops = per_launch.get(dom, 0.0) / slices
         ach = flops / avg_s / 1e12 if flops else 0.0
-        # HBM bytes per launch of that kernel from the committed PMC passes of the same workload (rocprofv3 cannot run
-        # inside this process); null when no committed pass matches the batch size
+        # HBM bytes per launch of that kernel from the committed PMC passes of the same workload (rocprofv3 cannot run inside this
+        # process).  The summary records the SHA-1 of the library it was measured on: another build -> null, not a stale number
         traffic, traffic_src = None, None
         try:
             name = "pmc_traffic.json" if args.batch == 256 else f"pmc_traffic_b{args.batch}.json"
             pmc = json.load(open(os.path.join(ROOT, "profiles", PROFILE_DIR, name)))
-            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-            traffic_src = f"profiles/{PROFILE_DIR}/{name} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            if pmc.get("lib_sha16") and pmc.get("lib_sha16") == lib_sha16() and not args.opt and not args.knn:
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{PROFILE_DIR}/{name} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, library {pmc['lib_sha16']})"
         except Exception:
             pass
-        # matrix instructions the dominant kernel really issues (f16 or bf16 piece products), against the 2.5 PFLOP/s peak
-        pieces = {"edge_x2h": 3 * 2 * (2 * HH + 2 * 32 * dm.H) * dm.k * n_atoms,
-                  "edge_h2x": 3 * 2 * ((HH + 32 * dm.H) + (16 * dm.H + 32 * dm.H)) * dm.k * n_atoms,
-                  "node_chain": 3 * 14 * HH * n_atoms, "node_pre": 3 * 16 * HH * n_atoms}
+        # matrix instructions the dominant kernel really issues (bf16 piece products, K padding of the RBF block included), against
+        # the 2.5 PFLOP/s dense bf16 peak
+        PP = PIECE_PRODUCTS
+        pieces = {"edge_x2h": PP * 2 * (2 * HH + 2 * 32 * dm.H) * dm.k * n_atoms,
+                  "edge_h2x": PP * 2 * ((HH + 32 * dm.H) + (16 * dm.H + 32 * dm.H)) * dm.k * n_atoms,
+                  "node_chain": PP * 14 * HH * n_atoms, "node_pre": PP * 16 * HH * n_atoms}
         pieces["edge_x2h_chain"] = pieces["edge_x2h"] + pieces["node_chain"]
         pieces = pieces.get(dom)
         if pieces:
             pieces /= slices
         step_exec = f_exec_total * n_atoms / sec_per_step / 1e12
-        # ceiling of the formulation the kernel runs: every fp32 product is three f16 (edge, node) piece products on the
-        # f16 matrix cores, so the algorithm's fp32 FLOPs are bounded by the dense f16 peak / 3
-        peak_equiv = F16_MFMA_PEAK_TFLOPS / 3.0
+        # ceiling of the formulation the kernel runs: every fp32 product is six bf16 piece products on the matrix cores, so the
+        # algorithm's fp32 FLOPs are bounded by the dense bf16 peak / 6
+        peak_equiv = F16_MFMA_PEAK_TFLOPS / PP
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": round(peak_equiv, 1), "unit": "TFLOP/s",
-            "frac": round(ach / peak_equiv, 4), "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+            "frac": round(ach / peak_equiv, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "hbm_frac": (round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
             "matrix_pipe_frac": (round(pieces / avg_s / 1e12 / F16_MFMA_PEAK_TFLOPS, 4) if pieces else None),
-            "step_frac": round(step_exec / FP32_MFMA_PEAK_TFLOPS, 4),
             "flops_per_launch_executed": flops, "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_n,
             "share_of_step": round(dom_ms / tot_ms, 3),
             "timing": "begin/end timestamps of the kernel dispatches (hipExtLaunchKernelGGL start/stop events), eager pass "
                       f"of {max(1, args.profile_steps)} steps right after the timed region; rocprofv3 --kernel-trace --stats of the "
                       f"same command: profiles/{PROFILE_DIR}/kernel_stats.csv",
-            "note": "achieved: fp32 FLOPs of the kernel's algorithm (factorised first Linears) per second; peak: the dense f16 MFMA peak "
-                    "(2.5 PFLOP/s) / 3, because each fp32 product is evaluated as three f16 piece products (22-bit operands, fp32 "
-                    "accumulate) -- frac_of_fp32_mfma_peak compares the same rate with the 157.3 TFLOP/s fp32 matrix peak it no longer uses. "
-                    "The step is latency-bound (27 dependent launches of 7-31 us on 5.5k atoms at B = 256), not bound by either roof: "
-                    "hbm_frac = PMC HBM bytes per launch / launch time / 8 TB/s, matrix_pipe_frac = f16/bf16 piece-product FLOPs "
-                    "actually issued / 2.5 PFLOP/s, step_frac = executed fp32 FLOPs of the whole step / step time / fp32 peak",
+            "note": "achieved: fp32 FLOPs of the kernel's algorithm (factorised first Linears) per second; peak: the dense bf16 MFMA peak "
+                    "(2.5 PFLOP/s) / 6, because each fp32 product is evaluated exactly as six bf16 piece products (24-bit operands, fp32 "
+                    "accumulate).  matrix_pipe_frac = bf16 piece-product FLOPs actually issued (K padding included) / 2.5 PFLOP/s; "
+                    "hbm_frac = PMC HBM bytes per launch / launch time / 8 TB/s (Infinity-Cache resident re-reads, not a binding roof)",
             "step_tflops_executed": round(step_exec, 3),
             "step_tflops_ref_equiv": round(reference_flops_per_atom_step(dm.k, dm.L) * n_atoms / sec_per_step / 1e12, 3),
             "breakdown_ms_per_step": {k: round(v[0] / max(1, args.profile_steps), 4) for k, v in prof.items()},
@@ -333,44 +348,36 @@ def main():
                                         "note": "independent batch-256 chains (own batch-norm statistics each) on separate streams of one GPU"}
             log(f"concurrent chains: {out['concurrent_chains']}")
             del runners
-        # ---- the same chain with exactly split operands (fp32-exact products), driver-timed like `value` ----
-        if world == 1 and args.exact_steps > 0 and use_graph and not args.opt and cfg["knn"] <= 16:       # (k > 16 has no bf16 path)
+        # ---- optional modes, driver-timed like `value`, never `value`: two-piece f16 operands (22-23 bits, three products) and
+        #      "f16 features" (single f16 pieces, 11 bits; BASELINE configs[2] names a reduced-precision feature mode) ----
+        def timed_mode(options, restore, seed):
             es = min(args.exact_steps, runner.max_steps)
-            model.set_option("edge_bf16", 1)
-            model.set_option("node_f16", 0)
+            for k_, v_ in options:
+                model.set_option(k_, v_)
             try:
-                runner.run(max(1, min(warm, es), min(clock_warm, runner.max_steps)), seed=31, use_graph=True)   # re-captures the step graph with these kernels; loaded clocks
+                runner.run(max(1, min(warm, es), min(clock_warm, runner.max_steps)), seed=seed, use_graph=True)   # re-captures the step graph with these kernels; loaded clocks
                 runner.synchronize()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                runner.run(es, seed=32, use_graph=True)
+                runner.run(es, seed=seed + 1, use_graph=True)
                 runner.synchronize()
                 dte = (time.perf_counter() - t1) / es
-                out["exact_mode"] = {"value": round(args.batch / (CHAIN_STEPS * dte), 3), "unit": "molecules/s", "ms_per_step": round(dte * 1e3, 4),
-                                     "steps": es, "dtype": "f32 (matrix operands as 3 x bf16 pieces = 24 bits, exact; six products, fp32 accumulate)",
-                                     "options": ["edge_bf16=1", "node_f16=0"]}
-                log(f"exact mode: {out['exact_mode']}")
             finally:
-                model.set_option("edge_bf16", 3)
-                model.set_option("node_f16", 1)
-        # ---- reduced precision: "f16 features" (BASELINE configs[2] names a reduced-precision feature mode; NOT a parity mode) ----
+                for k_, v_ in restore:
+                    model.set_option(k_, v_)
+            return {"value": round(args.batch / (CHAIN_STEPS * dte), 3), "unit": "molecules/s", "ms_per_step": round(dte * 1e3, 4), "steps": es,
+                    "options": [f"{k_}={v_}" for k_, v_ in options]}
+
         if world == 1 and args.exact_steps > 0 and use_graph and not args.opt:
-            es = min(args.exact_steps, runner.max_steps)
-            model.set_option("feat_f16", 1)
-            try:
-                runner.run(max(1, min(warm, es), min(clock_warm, runner.max_steps)), seed=41, use_graph=True)
-                runner.synchronize()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                runner.run(es, seed=42, use_graph=True)
-                runner.synchronize()
-                dtf = (time.perf_counter() - t1) / es
-                out["f16_features_mode"] = {"value": round(args.batch / (CHAIN_STEPS * dtf), 3), "unit": "molecules/s", "ms_per_step": round(dtf * 1e3, 4),
-                                            "steps": es, "dtype": "f16 matrix operands (11 bits, one product per term), fp32 accumulate / LayerNorm / softmax / coordinates",
-                                            "options": ["feat_f16=1"], "note": "reduced precision, outside the parity gates (forward error ~1e-3)"}
-                log(f"f16 features mode: {out['f16_features_mode']}")
-            finally:
-                model.set_option("feat_f16", 0)
+            out["f16x2_mode"] = dict(timed_mode([("edge_bf16", 3), ("node_f16", 1)], [("node_f16", 0), ("edge_bf16", 2)], 31),
+                                     dtype="f32 (matrix operands as 2 x f16 pieces: error <= 2^-22 |x| per operand, absolute floor 2^-25 for |x| < 2^-3; "
+                                           "three products, fp32 accumulate)",
+                                     note="the round-2/3 kernels; passes the same parity gates, NOT reference operand precision")
+            log(f"f16x2 mode: {out['f16x2_mode']}")
+            out["f16_features_mode"] = dict(timed_mode([("edge_bf16", 3), ("node_f16", 1), ("feat_f16", 1)], [("feat_f16", 0), ("node_f16", 0), ("edge_bf16", 2)], 41),
+                                            dtype="f16 matrix operands (11 bits, one product per term), fp32 accumulate / LayerNorm / softmax / coordinates",
+                                            note="reduced precision, outside the parity gates (forward error ~1e-3)")
+            log(f"f16 features mode: {out['f16_features_mode']}")
         # trajectory D2H cost (reported, never part of value)
         if not args.no_traj:
             torch.cuda.synchronize()

@@ -27,6 +27,16 @@ def set_mode(m, mode):
     return m
 
 
+_memo = {}
+
+
+def memo(key, fn):
+    """CPU-oracle results shared by the precision-mode variants of a test (the oracle does not depend on the mode)."""
+    if key not in _memo:
+        _memo[key] = fn()
+    return _memo[key]
+
+
 def hip(mode, **kw):
     """The cached HIP model with a precision mode selected (restored to the defaults after the test by _restore_modes)."""
     return set_mode(hip_model(**kw), mode)
@@ -190,9 +200,11 @@ def test_forward_b256_vs_oracle(mode):
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(256, seed=2021)
     t = (synth.hash_u24(256, 9, 9) % 1000).astype(np.int64)
-    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    ref = memo("b256_fwd", lambda: O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t)))
     with torch.no_grad():
         out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
+    from util import record
+    record("forward_b256_vs_oracle", mode=mode, **{k: maxabs(out[k], ref[k]) for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v")})
     for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v"):
         assert maxabs(out[k], ref[k]) < FWD_TOL, k
     # the same evaluation with ONE wave per workgroup of the edge kernels: ~11 jobs per wave instead of one, i.e. the
@@ -262,8 +274,8 @@ def test_chain_b256_vs_oracle_30_steps(mode):
     bb = synth.synthetic_batch(256, seed=2021)
     n, S = len(bb["batch"]), 30
     eps, u = hash_noise(n, S, 2021)
-    ref = O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S,
-                         lambda s: (eps[s], u[s]), keep_traj=False)
+    ref = memo("chain_b256_30", lambda: O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S,
+                                                       lambda s: (eps[s], u[s]), keep_traj=False))
     r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u, return_traj=False)
     assert np.array_equal(r["v"].cpu().numpy(), ref["v"].numpy())
     assert maxabs(r["pos"], ref["pos"]) < POS_TOL
@@ -479,7 +491,7 @@ def test_forward_b1024_vs_oracle(mode):
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(1024, seed=14, max_atoms=38)
     t = (synth.hash_u24(1024, 9, 14) % 1000).astype(np.int64)
-    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    ref = memo("b1024_fwd", lambda: O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t)))
     with torch.no_grad():
         out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
     errs = {k: maxabs(out[k], ref[k]) for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v")}
@@ -686,7 +698,7 @@ def test_forward_k32_b512_vs_oracle(mode):
     bb = synth.synthetic_batch(B, seed=4096, atoms_range=(40, 80))
     n = len(bb["batch"])
     t = (synth.hash_u24(B, 79, 2) % 1000).astype(np.int64)
-    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    ref = memo("k32_b512_fwd", lambda: O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t)))
     with torch.no_grad():
         out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
     errs = {k: maxabs(out[k], ref[k]) for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v")}
@@ -716,7 +728,7 @@ def test_forward_b1024_edge_tile_variants(tiles):
     sd, dm, _, _ = oracle_model()
     bb = synth.synthetic_batch(1024, seed=14, max_atoms=38)
     t = (synth.hash_u24(1024, 9, 14) % 1000).astype(np.int64)
-    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    ref = memo("b1024_fwd", lambda: O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t)))
     try:
         m.set_option("edge_tiles", tiles)
         with torch.no_grad():
@@ -1455,14 +1467,14 @@ def test_forward_and_chain_b4096_vs_oracle(mode):
     bb = synth.synthetic_batch(B, seed=4097, max_atoms=38)
     n = len(bb["batch"])
     t = (synth.hash_u24(B, 80, 3) % 1000).astype(np.int64)
-    ref = O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t))
+    ref = memo("b4096_fwd", lambda: O.score(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), T(t)))
     with torch.no_grad():
         out = m(T(bb["init_pos"], DEV), T(bb["init_v"], DEV), T(bb["batch"], DEV), T(bb["shape"], DEV), T(t, DEV))
     errs = {k: maxabs(out[k], ref[k]) for k in ("pred_ligand_pos", "pred_ligand_h", "pred_ligand_v")}
     S = 1
     eps, u = hash_noise(n, S, 4097)
     r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u)
-    ro = O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S, lambda s_: (eps[s_], u[s_]), keep_traj=False)
+    ro = memo("b4096_chain", lambda: O.sample_chain(sd, dm, T(bb["init_pos"]), T(bb["init_v"]), T(bb["batch"]), T(bb["shape"]), S, lambda s_: (eps[s_], u[s_]), keep_traj=False))
     errs["chain_pos"] = maxabs(r["pos"], ro["pos"])
     record("forward_and_chain_b4096_vs_oracle", mode=mode, n_atoms=n, **errs)
     assert np.array_equal(r["v"].cpu().numpy(), ro["v"].numpy())

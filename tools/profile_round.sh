@@ -9,6 +9,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 SHORT="--steps 20 --warmup 5 --clock-warmup 0 --cpu-steps 0 --profile-steps 2 --eager --concurrent 0 --exact-steps 0"
 find_csv() { find "$1" -name "*$2" | head -1; }
+LIBSHA=$(sha1sum shapemol_amd/libshapemol_hip.so | cut -c1-16)
 
 for B in 256 1024; do
   tag=$([ $B = 256 ] && echo "" || echo "_b$B")
@@ -20,7 +21,7 @@ for B in 256 1024; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_${C}$tag" -- python3 bench.py --batch $B $SHORT > /dev/null 2> "$OUT/pmc_${C}$tag.err"
   done
-  python3 tools/pmc_traffic.py "$(find_csv "$OUT/pmc_FETCH_SIZE$tag" _counter_collection.csv)" "$(find_csv "$OUT/pmc_WRITE_SIZE$tag" _counter_collection.csv)" > "$OUT/pmc_traffic$tag.json"
+  python3 tools/pmc_traffic.py "$(find_csv "$OUT/pmc_FETCH_SIZE$tag" _counter_collection.csv)" "$(find_csv "$OUT/pmc_WRITE_SIZE$tag" _counter_collection.csv)" "$LIBSHA" > "$OUT/pmc_traffic$tag.json"
   echo "B=$B done" >&2
 done
 
@@ -39,7 +40,7 @@ for SET in "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_
 done
 echo "sq done" >&2
 
-mkdir -p profiles/r03 && cp "$OUT"/pmc_traffic*.json profiles/r03/      # bench.py reads its `traffic` field from the committed summaries
+mkdir -p profiles/r04 && cp "$OUT"/pmc_traffic*.json profiles/r04/      # bench.py reads its `traffic` field from the committed summaries (keyed to the library's SHA-1)
 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_line_20steps.json" 2> "$OUT/bench_line_20steps.err"
 python3 bench.py --batch 1024 --steps 100 --cpu-steps 0 > "$OUT/bench_line_b1024.json" 2> "$OUT/bench_line_b1024.err"
