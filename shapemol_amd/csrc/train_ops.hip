@@ -72,7 +72,8 @@ int ln_backward(hipStream_t s, float *dz, const float *xhat, const float *rstd, 
     return reduce_parts3(s, pln, nwg, H, dgamma, dbeta, db1);
 }
 bool bad_dims(int64_t rows, int k_in, int hidden, int n_out) {
-    return rows < 1 || rows > (1ll << 26) || k_in < 1 || k_in > 4096 || hidden < 1 || hidden > kMaxHidden || n_out < 1 || n_out > 4096;
+    // rows: gemm() puts ceil(rows / 64) on grid.y, which HIP limits to 65535 (4.19 M rows: 8x the edges of a B = 4096 batch)
+    return rows < 1 || rows > 65535ll * 64 || k_in < 1 || k_in > 4096 || hidden < 1 || hidden > kMaxHidden || n_out < 1 || n_out > 4096;
 }
 }  // namespace
 
@@ -149,7 +150,7 @@ int shapemol_mlp_backward(const float *d_x, const float *d_dy, int64_t rows, int
 // backward sums dz over each atom's edges before its node-level products.
 struct EdgeDims { int64_t E, N; int kr, H, Si, hidden, n_out, K1; };
 static bool bad_edge_dims(const EdgeDims &d) {
-    return d.E < 1 || d.E > (1ll << 26) || d.N < 1 || d.N > (1ll << 26) || d.kr < 1 || d.kr > 1024 || d.H < 1 || d.H > 1024 || d.Si < 0 || d.Si > 1024 ||
+    return d.E < 1 || d.E > 65535ll * 64 || d.N < 1 || d.N > 65535ll * 64 || d.kr < 1 || d.kr > 1024 || d.H < 1 || d.H > 1024 || d.Si < 0 || d.Si > 1024 ||
            d.hidden < 1 || d.hidden > kMaxHidden || d.n_out < 1 || d.n_out > 4096;
 }
 struct EdgeWork { size_t act, dz, dpd, dps, part, pln, pb, gb, total; };
@@ -256,7 +257,10 @@ int shapemol_edge_mlp_backward(const float *d_r, const float *d_h, const float *
 
 // ---- the coordinate update's vector-neuron block (VNLinearLeakyReLU + VNBatchNorm + mean over channels), sm_train.h
 static bool bad_vn_dims(int64_t n, int rows_o, int rows_s, int C) {
-    return n < 1 || n > (1ll << 26) || rows_o < 0 || rows_o > 256 || rows_s < 0 || rows_s > 1024 || C < 1 || C > 64;
+    // the VN kernels stage 2 C (1 + rows_o + rows_s) weights (and, backward, 2 * per-thread tiles) in dynamic LDS without raising the
+    // 64 KB default limit: keep the weight block within 48 KB
+    if (n < 1 || n > 65535ll * 64 || rows_o < 0 || rows_o > 256 || rows_s < 0 || rows_s > 1024 || C < 1 || C > 64) return true;
+    return (size_t)2 * C * (1 + rows_o + rows_s) * sizeof(float) > 48 * 1024;
 }
 size_t shapemol_vn_backward_workspace(int64_t n_atoms, int32_t rows_o, int32_t rows_s, int32_t channels) {
     if (bad_vn_dims(n_atoms, rows_o, rows_s, channels)) return 0;

@@ -185,59 +185,70 @@ def sample_diffusion_ligand(model, shape_emb, num_samples, batch_size=16, device
             all_pred_vt_traj += take("vt_traj")
         time_list.append(time.time() - t1)
 
-    for slot_i, i in enumerate(range(num_batch) if _batches is None else _batches):
-        n_data = batch_size if i < num_batch - 1 else num_samples - batch_size * (num_batch - 1)
-        t1 = time.time()
-        if _batch_seed is not None:
-            np.random.seed((int(_batch_seed) + i) % (2 ** 32))
-            torch.manual_seed(int(_batch_seed) + i)
-        if sample_num_atoms == "size":
-            assert sample_func is not None
-            ligand_num_atoms = [int(x) for x in sample_func(n_data)]
-        elif sample_num_atoms == "ref":
-            assert ref_num_atoms is not None
-            ligand_num_atoms = [int(ref_num_atoms)] * n_data
-        else:
-            raise ValueError
-        batch_ligand = torch.repeat_interleave(torch.arange(n_data), torch.tensor(ligand_num_atoms)).to(dev)
-        all_ligand_atoms = sum(ligand_num_atoms)
-        init_ligand_pos = torch.randn(all_ligand_atoms, 3).to(dev)            # host generator, as the reference
-        if pos_only:
-            if sample_num_atoms != "ref" or ref_atom_feature is None:
-                raise ValueError("pos_only keeps the reference atom types: needs sample_num_atoms='ref' and ref_atom_feature")
-            init_ligand_v = torch.as_tensor(ref_atom_feature, dtype=torch.int64).repeat(n_data).to(dev)
-        else:
-            if getattr(model, "v_mode", "categorical") == "gaussian":
-                raise NotImplementedError("v_mode 'gaussian' is not part of the accelerated path")
-            uniform_logits = torch.zeros(len(batch_ligand), model.num_classes, device=dev)
-            if host_rng:
-                init_ligand_v = log_sample_categorical(uniform_logits, u=torch.rand(all_ligand_atoms, model.num_classes).to(dev))
+    try:
+        for slot_i, i in enumerate(range(num_batch) if _batches is None else _batches):
+            n_data = batch_size if i < num_batch - 1 else num_samples - batch_size * (num_batch - 1)
+            t1 = time.time()
+            if _batch_seed is not None:
+                np.random.seed((int(_batch_seed) + i) % (2 ** 32))
+                torch.manual_seed(int(_batch_seed) + i)
+            if sample_num_atoms == "size":
+                assert sample_func is not None
+                ligand_num_atoms = [int(x) for x in sample_func(n_data)]
+            elif sample_num_atoms == "ref":
+                assert ref_num_atoms is not None
+                ligand_num_atoms = [int(ref_num_atoms)] * n_data
             else:
-                init_ligand_v = log_sample_categorical(uniform_logits)
-        noise_kw = {}
-        if host_rng:
-            if not accelerated:
-                raise ValueError("host_rng feeds recorded draws to the device chain: it needs the accelerated model")
-            n_steps = num_steps if num_steps is not None else model.num_timesteps
-            eps = torch.empty(n_steps, all_ligand_atoms, 3)
-            uu = torch.empty(n_steps, all_ligand_atoms, model.num_classes)
-            for s_ in range(n_steps):                    # one reverse step at a time: the two streams interleave
-                eps[s_] = torch.randn(all_ligand_atoms, 3)
-                uu[s_] = torch.rand(all_ligand_atoms, model.num_classes)
-            noise_kw["noise"] = (eps.to(dev), uu.to(dev))
-        while len(pending) >= depth:                     # the slot this batch will use must be free again
+                raise ValueError
+            batch_ligand = torch.repeat_interleave(torch.arange(n_data), torch.tensor(ligand_num_atoms)).to(dev)
+            all_ligand_atoms = sum(ligand_num_atoms)
+            init_ligand_pos = torch.randn(all_ligand_atoms, 3).to(dev)            # host generator, as the reference
+            if pos_only:
+                if sample_num_atoms != "ref" or ref_atom_feature is None:
+                    raise ValueError("pos_only keeps the reference atom types: needs sample_num_atoms='ref' and ref_atom_feature")
+                init_ligand_v = torch.as_tensor(ref_atom_feature, dtype=torch.int64).repeat(n_data).to(dev)
+            else:
+                if getattr(model, "v_mode", "categorical") == "gaussian":
+                    raise NotImplementedError("v_mode 'gaussian' is not part of the accelerated path")
+                uniform_logits = torch.zeros(len(batch_ligand), model.num_classes, device=dev)
+                if host_rng:
+                    init_ligand_v = log_sample_categorical(uniform_logits, u=torch.rand(all_ligand_atoms, model.num_classes).to(dev))
+                else:
+                    init_ligand_v = log_sample_categorical(uniform_logits)
+            noise_kw = {}
+            if host_rng:
+                if not accelerated:
+                    raise ValueError("host_rng feeds recorded draws to the device chain: it needs the accelerated model")
+                n_steps = num_steps if num_steps is not None else model.num_timesteps
+                eps = torch.empty(n_steps, all_ligand_atoms, 3)
+                uu = torch.empty(n_steps, all_ligand_atoms, model.num_classes)
+                for s_ in range(n_steps):                    # one reverse step at a time: the two streams interleave
+                    eps[s_] = torch.randn(all_ligand_atoms, 3)
+                    uu[s_] = torch.rand(all_ligand_atoms, model.num_classes)
+                noise_kw["noise"] = (eps.to(dev), uu.to(dev))
+            while len(pending) >= depth:                     # the slot this batch will use must be free again
+                deliver(pending.popleft())
+            handle = model.sample_diffusion(
+                init_ligand_pos=init_ligand_pos, init_ligand_v=init_ligand_v, batch_ligand=batch_ligand,
+                ligand_shape=(shape_emb if per_mol_shapes else shape_emb.repeat(n_data, 1, 1)).to(dev).reshape(n_data, -1),
+                threshold_type=threshold_type, threshold_args=threshold_args, num_steps=num_steps,
+                center_pos_mode=center_pos_mode, guide_stren=guide_stren, bounds=bounds,
+                use_pointcloud_data=use_pointcloud_data, grad_step=grad_step,
+                seed=None if seed is None else int(seed) + i, use_graph=use_graph, **noise_kw,
+                **({"_reuse_host_buffers": "device", "_slot": slot_i % depth, "_async": True} if accelerated else {}))
+            pending.append((handle, ligand_num_atoms, n_data, t1))
+        while pending:
             deliver(pending.popleft())
-        handle = model.sample_diffusion(
-            init_ligand_pos=init_ligand_pos, init_ligand_v=init_ligand_v, batch_ligand=batch_ligand,
-            ligand_shape=(shape_emb if per_mol_shapes else shape_emb.repeat(n_data, 1, 1)).to(dev).reshape(n_data, -1),
-            threshold_type=threshold_type, threshold_args=threshold_args, num_steps=num_steps,
-            center_pos_mode=center_pos_mode, guide_stren=guide_stren, bounds=bounds,
-            use_pointcloud_data=use_pointcloud_data, grad_step=grad_step,
-            seed=None if seed is None else int(seed) + i, use_graph=use_graph, **noise_kw,
-            **({"_reuse_host_buffers": "device", "_slot": slot_i % depth, "_async": True} if accelerated else {}))
-        pending.append((handle, ligand_num_atoms, n_data, t1))
-    while pending:
-        deliver(pending.popleft())
+    finally:
+        # an exception on the way (a failed delivery, an interrupt): the chains still in flight own a context slot and its
+        # buffers -- wait for them and drop their results instead of leaving them enqueued behind the caller's back
+        while pending:
+            h = pending.popleft()[0]
+            try:
+                if hasattr(h, "abandon"):
+                    h.abandon()
+            except Exception:
+                pass
     return (all_pred_pos, all_pred_v, all_pred_pos_traj, all_pred_v_traj, all_pred_v0_traj, all_pred_vt_traj, time_list,
             all_pred_pos_cond_traj, all_pred_v_cond_traj)
 

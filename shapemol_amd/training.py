@@ -214,6 +214,8 @@ class HipVN(torch.autograd.Function):
                                                  int(bool(training)), _p(out), _p(pf), _p(dr), _p(stats), _p(nrm),
                                                  C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         _lib.check(rc, "shapemol_vn_forward")
+        if training:      # the kernel wrote the running estimates through raw pointers: bump their version counters, so that whoever
+            run_mean.add_(0); run_var.add_(0)      # keys a cache on (data_ptr, _version) -- the validation context of the model -- sees the update
         ctx.save_for_backward(x, o3, shape, batch, *ws, pf, dr, stats)
         ctx.dims = (n, rows_o, rows_s, ch, int(bool(training)))
         return out
@@ -252,8 +254,14 @@ def knn_edges(x, batch, k):
     """Per-molecule k nearest neighbours on the device (self excluded; ties by (squared distance, index), the squared
     distance evaluated as (dx*dx + dy*dy) + dz*dz like the sampling kernels): (src = j, dst = i), grouped by centre i, and the CSR offsets of the groups (``batch`` sorted, as the reference's collate emits it)."""
     n = x.shape[0]
+    if n == 0:
+        raise ValueError("knn_edges: empty batch")
+    if bool((batch[1:] < batch[:-1]).any()):
+        raise ValueError("knn_edges: the batch vector must be sorted (atoms of a molecule contiguous), as the sampling path requires")
     counts = torch.bincount(batch)
     B, M = counts.shape[0], int(counts.max())
+    if M >= 65536:
+        raise ValueError("knn_edges: molecules of 65536 atoms or more are not supported (the tie-breaking index takes 16 bits of the key)")
     first = torch.cumsum(counts, 0) - counts
     local = torch.arange(n, device=x.device) - first[batch]
     pad = torch.zeros((B, M, 3), dtype=x.dtype, device=x.device)
