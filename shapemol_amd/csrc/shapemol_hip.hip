@@ -380,7 +380,7 @@ size_t pack_linear16_image(Image &im, size_t src, int rows, int K) {
 }
 
 // one edge MLP -> the producer part of the streaming kernels (StreamMap<H, .>::P_*, sm_edge_stream.h): RBF block of the first
-// Linear as three bf16 pieces (three words of the K = 32 step: centres 0..5 of lane group g in words 0..2), gamma, beta, b2 and,
+// Linear as three bf16 pieces (whole A fragments of the K = 32 step: centres 0..5 of lane group g in words 0..2, word 3 zero), gamma, beta, b2 and,
 // for the heads-wide value MLP of h2x, the second Linear (rows = heads in natural order, padded to 16)
 template <int H>
 size_t pack_stream_part(Image &im, const Mlp &m, int kv_in, bool h2x_value) {
@@ -399,7 +399,7 @@ size_t pack_stream_part(Image &im, const Mlp &m, int kv_in, bool h2x_value) {
                     split3_host(j < 5 ? m.l1.w[(size_t)(16 * t + (lane & 15)) * kv_in + 4 * j + (lane >> 4)] : 0.f, pc[e]);
                 }
                 for (int piece = 0; piece < 3; ++piece)
-                    d[MX::P_W1 + ((size_t)(piece * NT + t) * 64 + lane) * 3 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);
+                    d[MX::P_W1 + ((size_t)(piece * NT + t) * 64 + lane) * 4 + q] = (uint32_t)pc[0][piece] | ((uint32_t)pc[1][piece] << 16);      // (word 3 stays zero)
             }
     float *pp = &im.d[o];
     std::memcpy(pp + MX::P_G, m.g, H * sizeof(float));

@@ -50,25 +50,20 @@ struct EdgeStreamArgs {
 };
 
 constexpr int kStreamProducers = 4, kStreamTPR = 2;      // producer waves; tiles per round
-#ifndef SM_STREAM_EARLY
-#define SM_STREAM_EARLY 0        // experiment: request the next unit's rows right after the current rows are summed
-#endif
 #ifndef SM_STREAM_ABL
 #define SM_STREAM_ABL 0          // timing attribution builds only (bit 0: consumers skip their matrix products, 1: producers skip the
 #endif                           // first Linear's products, 2: producers skip LayerNorm, 3: producers skip the split, 4: no s_setprio for producers)
 #define SM_SABL(bit) (((SM_STREAM_ABL) >> (bit)) & 1)
-#ifndef SM_STREAM_TOUCH
-#define SM_STREAM_TOUCH 0        // experiment: consumers warm the L2 with the later rounds' rows while the producers work on round 0
-#endif
 
 // dynamic LDS map in 32-bit words
 template <int H, bool H2X>
 struct StreamMap {
     static constexpr int NT = H / 16, NB = NT / 2, NM = H2X ? 1 : 2, TPR = kStreamTPR;
     // producer part of one MLP (the global image is copied verbatim)
-    static constexpr int P_W1 = 0;                               // RBF block of the first Linear: [3 pieces][NT][64][3] u32 (K = 20 -> 32; the
-                                                                 // fourth word of the A fragment is always zero and not stored)
-    static constexpr int P_G = 3 * NT * 192, P_B = P_G + H, P_B2 = P_B + H;      // gamma[H] | beta[H] | b2 (h2x value: [16])
+    static constexpr int P_W1 = 0;                               // RBF block of the first Linear: [3 pieces][NT][64][4] u32 (K = 20 -> 32: whole A
+                                                                 // fragments, the fourth word zero: one 16-byte LDS read per fragment
+                                                                 // instead of an 8- and a 4-byte one -- 24 fewer LDS instructions per unit)
+    static constexpr int P_G = 3 * NT * 256, P_B = P_G + H, P_B2 = P_B + H;      // gamma[H] | beta[H] | b2 (h2x value: [16])
     static constexpr int P_W2 = P_B2 + H;                        // h2x value only: [3 pieces][NB][64][4] u32, rows = heads
     static constexpr int PART_K = (P_W2 + 255) / 256 * 256;
     static constexpr int PART_V = (P_W2 + (H2X ? 3 * NB * 256 : 0) + 255) / 256 * 256;
@@ -390,10 +385,6 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
                 request(tile_of(r + 1), jr);
             }
         };
-#if SM_STREAM_EARLY
-        // the rows have been consumed: request the next unit's at once (a whole unit of arithmetic plus the barrier to land in)
-        if constexpr (!(H2X && MLP == 1)) request_next();
-#endif
         // RBF block of the first Linear: one K = 32 step, six piece products per output tile
         {
             float cen[5], rb[5];
@@ -404,11 +395,10 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
             split3_pair(rb[0], rb[1], h_, m_, l_); rh[0] = h_; rm[0] = m_; rl[0] = l_;
             split3_pair(rb[2], rb[3], h_, m_, l_); rh[1] = h_; rm[1] = m_; rl[1] = l_;
             split3_pair(rb[4], 0.f, h_, m_, l_); rh[2] = h_; rm[2] = m_; rl[2] = l_;
-            const unsigned *w1 = reinterpret_cast<const unsigned *>(part) + M::P_W1 + lane * 3;
+            const u32x4 *w1 = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned *>(part) + M::P_W1) + lane;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const unsigned *ph = w1 + (0 * NT + t) * 192, *pm = w1 + (1 * NT + t) * 192, *pl = w1 + (2 * NT + t) * 192;
-                const u32x4 ah = {ph[0], ph[1], ph[2], 0u}, am = {pm[0], pm[1], pm[2], 0u}, al = {pl[0], pl[1], pl[2], 0u};
+                const u32x4 ah = w1[(0 * NT + t) * 64], am = w1[(1 * NT + t) * 64], al = w1[(2 * NT + t) * 64];
                 f32x4 c = acc[t];
                 if (!SM_SABL(1)) {
                 c = mfma_bf16(al, rh, c);      // smallest terms first
@@ -419,18 +409,13 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
                 c = mfma_bf16(ah, rh, c);
                 } else c[0] += __builtin_bit_cast(float, al[0] ^ am[1] ^ ah[2]) * __builtin_bit_cast(float, rh[0] ^ rm[1] ^ rl[2]);
                 acc[t] = c;
-#if SM_STREAM_EARLY
-                if (t % 2 == 1) __builtin_amdgcn_sched_barrier(0);     // (the next rows are in flight in 64 registers: keep the scheduler
-#endif                                                                  //  from reading every fragment of the block ahead)
             }
         }
         // the rows have been consumed and the first Linear's fragments are dead: request the next unit's rows (they fly under
         // the LayerNorm, the split and the barrier; the h2x value producer, which still has a matrix product ahead and needs
         // the registers for it, requests them behind that product)
         if (r == 1) SM_TICK(a.stamps, 5);
-#if !SM_STREAM_EARLY
         if constexpr (!(H2X && MLP == 1)) request_next();
-#endif
         float hid[NT * 4];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -500,24 +485,9 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
     const unsigned *ldsu = reinterpret_cast<const unsigned *>(lds);
     const int lane = G.lane, wave = G.wave, n = G.n, g = G.g, wg_first = G.wg_first, wg_end = G.wg_end, rounds = G.rounds;
     SM_TICK(a.stamps, 0);
-#if SM_STREAM_TOUCH
-    // Warm the L2 with the rows the producers will gather in the rounds after the first (the per-node products are tens of MB:
-    // a first touch comes from the Infinity Cache, 2-3 us away, and a producer has one round of look-ahead): the consumers
-    // have nothing to do until the first round is produced.  One load per 128-byte line, results discarded.
-    float touch = 0.f;
-    for (int tt = wg_first + TPR + wave; tt < wg_end; tt += GE::NCONS) {
-        const int ta = min(GE::atom_of(tt, n), a.n_atoms - 1);
-        const int tj = a.nbr[ta * KP + GE::slot_of(tt, n)];
-        const float *ra = a.pre + (size_t)ta * a.ld_pre + 32 * g, *rb = a.pre + (size_t)(tj >= 0 ? tj : ta) * a.ld_pre + H + 32 * g;
-        touch += ra[0] + rb[0] + ra[2 * H] + rb[2 * H];
-    }
-#endif
     int span0, span_n;
     stream_prologue<H, KP, H2X>(a, G, lds, span0, span_n);
     SM_TICK(a.stamps, 1);
-#if SM_STREAM_TOUCH
-    if (touch == 1.2345e-30f) a.out[0] = touch;      // (never true: keeps the loads)
-#endif
     // this wave's row block of the second Linears, in registers for the whole launch (loaded while the producers work on the
     // first round)
     u32x4 wk[3][NB], wv[3][NB];

@@ -2,7 +2,7 @@
 """Randomised parity sweep of the HIP path against the CPU oracle (GPU box): forwards and short chains over random batch
 sizes, molecule sizes, neighbour counts k and time steps, every kernel family the launch logic can pick (one-job and
 sliced f16 edge kernels, half-atom tiles + merge for k > 16, looping launches, folded and separate coordinate updates).
-    python tools/fuzz_parity.py [--cases 40] [--seed 1] > profiles/r03/fuzz_parity.txt"""
+    python tools/fuzz_parity.py [--cases 40] [--seed 1] > profiles/r04/fuzz_parity.txt      (the default = exact-operand mode: streaming edge kernels at every k)"""
 import argparse
 import os
 import sys

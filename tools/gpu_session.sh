@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 1100 bash tools/profile_round.sh gpurun_out/prof_r04 > gpurun_out/prof_r04.log 2>&1; tail -3 gpurun_out/prof_r04.log
-timeout -k 10 120 python tools/driver_bench.py > gpurun_out/driver_bench.json 2> gpurun_out/driver_bench.log; tail -2 gpurun_out/driver_bench.json
+timeout -k 10 200 python tools/mode_check.py --batch 256 --oracle > gpurun_out/mc256.log 2>&1; tail -3 gpurun_out/mc256.log
+timeout -k 10 600 python tools/fuzz_parity.py --cases 40 > gpurun_out/fuzz_parity.txt 2>&1; tail -4 gpurun_out/fuzz_parity.txt
+timeout -k 10 300 python tools/soak.py > gpurun_out/soak.txt 2>&1; tail -5 gpurun_out/soak.txt
