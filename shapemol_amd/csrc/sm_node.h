@@ -114,7 +114,7 @@ node_linear6_kernel(NodeLinArgs a) {
     u32x4 *frag = reinterpret_cast<u32x4 *>(lin6_lds);              // [tile][piece][NB][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int nwave = blockDim.x >> 6;
+    const int nwave = a.nwave;      // (reading blockDim costs two dependent loads from the implicit kernel arguments at the head of the launch)
     const int ogroups = (a.n_out_tiles + nwave - 1) / nwave;
     const int ot_raw = (blockIdx.x % ogroups) * nwave + wave;
     const bool ot_ok = ot_raw < a.n_out_tiles;
@@ -135,7 +135,7 @@ node_linear6_kernel(NodeLinArgs a) {
     for (int cb = ct0; cb < ct1; cb += kLin6Chunk) {
         const int nc = min(kLin6Chunk, ct1 - cb);
         __syncthreads();                                            // previous chunk fully consumed
-        for (int idx = threadIdx.x; idx < nc * NB * 64; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < nc * NB * 64; idx += nwave * 64) {
             const int sl = idx & 63, sb = (idx >> 6) % NB, sc = idx / (64 * NB);
             const int at = min((cb + sc) * 16 + (sl & 15), a.n_atoms - 1);
             const float *src = a.in + (size_t)at * H + 32 * sb + 4 * (sl >> 4);
@@ -792,9 +792,9 @@ node_prologue6_kernel(NodePrologueArgs a) {
     // ---- bookkeeping of the evaluation ------------------------------------------------------------------
     const int step = a.step_ptr ? *a.step_ptr : 0;
     {
-        const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+        const int gid = blockIdx.x * (H * 4) + threadIdx.x;           // (the launch uses H * 4 threads: no blockDim read)
         if (gid == 0 && a.step_ptr) *a.step_cur = step;
-        for (int i = gid; i < a.bn_acc_len; i += gridDim.x * blockDim.x) a.bn_acc[i] = 0.0;
+        for (int i = gid; i < a.bn_acc_len; i += gridDim.x * (H * 4)) a.bn_acc[i] = 0.0;
     }
     // ---- stage 0: embedding of the workgroup's atoms -> global h0 and LDS fragments ----------------------
     u32x4 wq1[3][NB], wl[3][NB];
@@ -804,22 +804,14 @@ node_prologue6_kernel(NodePrologueArgs a) {
         const int at_raw = (ct0 + sc) * 16 + (sl & 15);
         const int at = min(at_raw, a.n_atoms - 1);
         const int t = a.step_ptr ? a.t_first - step : a.t_mol[a.mol_of[at]];
-        const float *te = a.ttab + (size_t)t * a.D;
         const int vi = min(max((int)a.v[at], 0), a.C - 1);       // out-of-range types are flagged by v_check_kernel
         const int fa = 32 * sb + 4 * (sl >> 4);
         float vv[8];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {                      // y = (b + W[:, v]) + sum_k W[:, C + k] te[k], k ascending
-            const int f = fa + 16 * hf;
-            const float4 bb = ldg4(a.emb_b + f), wv = ldg4(a.emb_wT + (size_t)vi * H + f);
-            float y[4] = {bb.x + wv.x, bb.y + wv.y, bb.z + wv.z, bb.w + wv.w};
-            for (int k = 0; k < a.D; ++k) {
-                const float4 wk = ldg4(a.emb_wT + (size_t)(a.C + k) * H + f);
-                const float tk = te[k];
-                y[0] += wk.x * tk; y[1] += wk.y * tk; y[2] += wk.z * tk; y[3] += wk.w * tk;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) vv[4 * hf + j] = y[j];
+        {   // the precomputed row of (t, v) (emb_table_kernel, built once per context with the sum y = (b + W[:, v]) + sum_k W[:, C + k] te[k],
+            // k ascending, that the reference's Linear evaluates per atom: molopt_score_model.py:292-301)
+            const float *row = a.etab + ((size_t)t * a.C + vi) * H + fa;
+            const float4 r0 = ldg4(row), r1 = ldg4(row + 16);
+            vv[0] = r0.x; vv[1] = r0.y; vv[2] = r0.z; vv[3] = r0.w; vv[4] = r1.x; vv[5] = r1.y; vv[6] = r1.z; vv[7] = r1.w;
         }
         if (at_raw < a.n_atoms) {
             stg4(a.h_out + (size_t)at * H + fa, float4{vv[0], vv[1], vv[2], vv[3]});

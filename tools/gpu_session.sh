@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 200 python tools/mode_check.py --batch 256 --oracle > gpurun_out/mc256.log 2>&1; tail -3 gpurun_out/mc256.log
-timeout -k 10 600 python tools/fuzz_parity.py --cases 40 > gpurun_out/fuzz_parity.txt 2>&1; tail -4 gpurun_out/fuzz_parity.txt
-timeout -k 10 300 python tools/soak.py > gpurun_out/soak.txt 2>&1; tail -5 gpurun_out/soak.txt
+for i in 1 2; do
+timeout -k 10 200 python bench.py --steps 300 --warmup 20 --cpu-steps 0 --concurrent 0 --exact-steps 0 > gpurun_out/b_stream.json 2> gpurun_out/b_stream.log; tail -2 gpurun_out/b_stream.log
+done
+timeout -k 10 200 python bench.py --batch 1024 --steps 100 --warmup 20 --cpu-steps 0 --concurrent 0 --exact-steps 0 > gpurun_out/b_stream_1024.json 2> gpurun_out/b_stream_1024.log; tail -2 gpurun_out/b_stream_1024.log
