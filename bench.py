@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0              # HBM3E peak (same guide)
 PROFILE_DIR = "r04"          # profiles/<dir>/pmc_traffic*.json hold the PMC traffic of the kernels timed here
 CHAIN_STEPS = 1000                 # the metric is quoted for 1000-step chains
 # what the arithmetic is: fp32 inputs, outputs, accumulators and vector work; every matrix operand is split EXACTLY into three
-# bf16 pieces (8 + 8 + 8 = the 24 significand bits of fp32, full fp32 exponent range) and a product is the six piece products of
+# bf16 pieces (8 + 8 + 8 = the 24 significand bits of fp32, exact for every value of magnitude >= 2^-110) and a product is the six piece products of
 # total order <= 2 with fp32 accumulation: the dropped terms are below 2^-24 |x w|.  This is the library's default mode and what
 # `value` is measured on; `f16x2_mode` on the JSON line times the same chain with two-piece f16 operands (22-23 bits, three
 # products: the round-2/3 kernels), `f16_features_mode` with single f16 pieces (11 bits) -- optional modes, never `value`.

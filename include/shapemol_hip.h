@@ -292,6 +292,12 @@ int shapemol_set_option(shapemol_ctx *ctx, const char *name, int64_t value);
  * launches (the pinned rows are overwritten between them). */
 int shapemol_set_knn_pins(shapemol_ctx *ctx, const int32_t *h_off, int32_t n_steps, const int32_t *h_atom, const int32_t *h_nbr,
                           int64_t n_pins, int32_t k);
+/* Diagnostic (host only, no device needed): the exact three-way bf16 split of the default precision mode -- every matrix operand x is
+ * carried as hi + mid + lo with hi = x truncated to bf16, mid = (x - hi) truncated, lo = x - hi - mid (8 + 8 + 8 significand bits,
+ * fp32 exponent range), so that x == hi + mid + lo EXACTLY for every fp32 value of magnitude 2^-110 (7.7e-34) and above (below that the
+ * third piece falls under bf16's smallest subnormal and the error is bounded by 2^-133) (fp32 nn.Linear operands of the reference:
+ * models/common.py:47-67).  pieces: three bf16 bit patterns.  tests/test_host.py checks the identity over random and edge values. */
+void shapemol_debug_split_exact(float x, uint16_t *pieces);
 /* Copy an internal device buffer of the last _score to HOST memory (synchronises the device).
  * names: "nbr" (N,KP) i32, "ew" (N,KP) f32, "h" (N,H), "x" (N,3), "pre" (N,4H), "q" (N,H),
  *        "att" (N,H), "o3" (N,48), "bnstat" (L,16,2,heads) f64, "dims" (8,) i64,

@@ -18,7 +18,7 @@ EXPORTS = (
     "shapemol_destroy", "shapemol_reserve", "shapemol_score", "shapemol_sample",
     "shapemol_log_sample_categorical", "shapemol_set_option", "shapemol_debug_read",
     "shapemol_profile_begin", "shapemol_profile_end", "shapemol_status", "shapemol_status_stream", "shapemol_set_guidance", "shapemol_guide_points",
-    "shapemol_pointcloud_guidance", "shapemol_set_knn_pins",
+    "shapemol_pointcloud_guidance", "shapemol_set_knn_pins", "shapemol_debug_split_exact",
     "shapemol_mlp_backward_workspace", "shapemol_mlp_forward", "shapemol_mlp_backward",
     "shapemol_seg_attention_forward", "shapemol_seg_attention_backward",
     "shapemol_vn_backward_workspace", "shapemol_vn_forward", "shapemol_vn_backward",
@@ -91,6 +91,8 @@ def load():
     lib.shapemol_set_guidance.argtypes = [vp, vp, i64, C.c_double, i32, vp]
     lib.shapemol_guide_points.argtypes = [vp, vp, i64, vp, u64, vp]
     lib.shapemol_set_knn_pins.argtypes = [vp, vp, i32, vp, vp, i64, i32]
+    lib.shapemol_debug_split_exact.argtypes = [C.c_float, vp]
+    lib.shapemol_debug_split_exact.restype = None
     lib.shapemol_pointcloud_guidance.argtypes = [vp, i64, C.c_double, C.c_double, vp, i64, vp, u64, vp]
     lib.shapemol_mlp_backward_workspace.restype = C.c_size_t
     lib.shapemol_mlp_backward_workspace.argtypes = [i64, i32, i32, i32]

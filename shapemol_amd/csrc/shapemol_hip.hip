@@ -1544,6 +1544,14 @@ int64_t shapemol_debug_read(shapemol_ctx *c, const char *name, void *dst, size_t
     return (int64_t)bytes;
 }
 
+/* Diagnostic: the exact three-way bf16 split the packers apply to every weight (and the kernels, with the same arithmetic, to every
+ * activation): pieces[0..2] = hi, mid, lo bit patterns, x == float(hi) + float(mid) + float(lo) exactly for |x| >= 2^-110. */
+void shapemol_debug_split_exact(float x, uint16_t *pieces) {
+    uint16_t p[3];
+    split3_host(x, p);
+    pieces[0] = p[0]; pieces[1] = p[1]; pieces[2] = p[2];
+}
+
 int shapemol_set_knn_pins(shapemol_ctx *c, const int32_t *h_off, int32_t n_steps, const int32_t *h_atom, const int32_t *h_nbr, int64_t n_pins, int32_t k) {
     if (!c) return fail("shapemol_set_knn_pins: null context");
     HIPCHK(hipSetDevice(c->device));

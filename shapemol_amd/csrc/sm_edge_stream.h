@@ -5,7 +5,7 @@
 // the centre atom, weighted neighbour sums.
 //
 // Arithmetic: every matrix operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits = the 24 of fp32, by
-// truncation, full fp32 exponent range: no scaling, no range restriction) and a product is the six piece products of total
+// truncation, full fp32 exponent range: exact for every value of magnitude >= 2^-110, no scaling) and a product is the six piece products of total
 // order <= 2 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (sm_device.h); the dropped terms are below 2^-24 |x w|.
 //
 // Structure (what is new): weights stationary in REGISTERS, activations streaming through LDS.

@@ -88,6 +88,35 @@ def test_library_exports_every_header_symbol():
     assert lib.shapemol_abi_version() == _lib.ABI_VERSION
 
 
+def test_exact_three_way_bf16_split_of_the_default_mode():
+    """The default precision mode carries every matrix operand as three bf16 pieces; the claim "the 24 significand bits of fp32,
+    exactly" is an identity, checked here on the packers' split (the kernels apply the same and / subtract sequence to
+    activations): hi + mid + lo == x bit for bit for every float from 2^-110 (7.7e-34: below that the third piece's bits fall
+    under bf16's smallest subnormal, 2^-133, and the error is bounded by it) up to the largest finite float -- random values over
+    the whole exponent range, exact powers of two, values with all 24 bits set."""
+    import ctypes as C
+    from shapemol_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+    bits = rs.randint(0, 2 ** 32, size=200000, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = x[np.isfinite(x)]
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -110, -(2.0 ** -109) * (1 + 2.0 ** -23), 3.4028234663852886e38, 1.0 + 2.0 ** -23, 1.9999998807907104,
+                     0.03, 0.1, 6.0e4, 1e-30, 16777215.0, 2.0 ** -149, 2.0 ** -126, 1e-36], np.float32)
+    out = (C.c_uint16 * 3)()
+    n_exact = 0
+    for v in np.concatenate([edge, x[:20000]]):
+        lib.shapemol_debug_split_exact(C.c_float(float(v)), out)
+        pieces = (np.array(list(out), np.uint32) << 16).view(np.float32)
+        total = np.float64(pieces[0]) + np.float64(pieces[1]) + np.float64(pieces[2])     # the three pieces do not overlap: exact in float64
+        if abs(float(v)) >= 2.0 ** -110 or v == 0.0:
+            assert total == np.float64(v), (v, pieces)
+            n_exact += 1
+        else:
+            assert abs(total - np.float64(v)) < 2.0 ** -133, (v, pieces)
+    assert n_exact > 15000
+
+
 def test_header_is_plain_c():
     """The boundary header is a C header (no C++ / HIP / torch types): it must compile as C99 with -Wall -Werror."""
     import shutil, subprocess
