@@ -18,6 +18,7 @@ because these take tens of CPU-minutes while make_golden.py's set regenerates in
     python tests/golden/make_golden_r2.py b1024_s1000   # round 3: configs[2]/[3] per-GPU batch at full length (~3 CPU-hours)
     python tests/golden/make_golden_r2.py center        # round 3: sample_diffusion(center_pos_mode='center') on off-centre molecules (seconds)
     python tests/golden/make_golden_r2.py b256_pins     # round 4: the b256 chain again, recording the reference's neighbour lists where the k-th / (k+1)-th choice is fragile
+    python tests/golden/make_golden_r2.py b1024_pins    # round 4: the same for the B = 1024 x 1000 chain (~3.5 CPU-hours)
 
 Noise is the hash noise of synth.step_noise (a pure function of (seed, step)), so the fixtures
 hold only the states: end pos / v, snapshots, and the first steps (so that the CPU suite can
@@ -373,16 +374,19 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     # float32 reductions of the CPU BLAS depend on the thread count: every fixture records the count it was made with
     # (the 47-minute B=256 chain ran on 6 threads beside a build, the k=32 set on 3), and a regeneration uses the same
-    threads = {"b256_pins": 6, "b256": 6, "b1024": 8, "k32": 3, "guide": 8, "se": 8, "loss": 8, "b256_tail": 6, "b1024_s1000": 5, "b512_k32": 6, "grad": 8}
+    threads = {"b256_pins": 6, "b1024_pins": 5, "b256": 6, "b1024": 8, "k32": 3, "guide": 8, "se": 8, "loss": 8, "b256_tail": 6, "b1024_s1000": 5, "b512_k32": 6, "grad": 8}
     def use_threads(task):
         torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", threads[task])))
     torch.set_num_threads(8)
-    if what in ("b256", "b1024", "b256_tail", "b1024_s1000", "b256_pins", "all"):
+    if what in ("b256", "b1024", "b256_tail", "b1024_s1000", "b256_pins", "b1024_pins", "all"):
         model, _ = G.load_reference_model()
         G.synthetic_load(model, seed=7)
         if what == "b256_pins":          # (not part of "all": a second 20-47 minute run of the b256 chain) round 4
             use_threads("b256_pins")
             chain_pins(model, "b256_s1000", "b256_s1000", max_atoms=38)
+        if what == "b1024_pins":         # (not part of "all": ~3.5 CPU-hours)
+            use_threads("b1024_pins")
+            chain_pins(model, "b1024_s1000", "b1024_s1000", max_atoms=38)
         if what == "b256_tail":          # (not part of "all": derived from the committed b256 chain, minutes)
             use_threads("b256_tail")
             chain_tail(model, "b256_s1000", "b256_s1000_tail", max_atoms=38)
