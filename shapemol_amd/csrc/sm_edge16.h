@@ -1,5 +1,5 @@
-// Edge attention with both Linears of the edge MLPs as THREE f16 MFMA products of two-piece operands (the default
-// kernels).  Same semantics and formulation as sm_edge_bf16.h (reference: models/uni_transformer.py:48-81 for x2h,
+// Edge attention with both Linears of the edge MLPs as THREE f16 MFMA products of two-piece operands (option edge_bf16 = 3: the
+// default of rounds 2-3, since round 4 the optional faster mode -- the default is the exactly split form of sm_edge_stream.h).  Same semantics and formulation as sm_edge_bf16.h (reference: models/uni_transformer.py:48-81 for x2h,
 // :121-151 for h2x); what changes is the arithmetic of the matrix products and, through it, the kernel's structure:
 //
 //   * a float is carried as hi + lo with hi = f16(x), lo = f16(x - hi), both round-to-nearest: 22 significand bits

@@ -1,4 +1,4 @@
-// Edge attention with the second Linear of the edge MLPs on the bf16 matrix cores (the default kernels).
+// Edge attention with the second Linear of the edge MLPs on the bf16 matrix cores (round 1's kernels; option edge_bf16 = 1).
 //
 // Same semantics and formulation as sm_edge.h (reference: models/uni_transformer.py:48-81 for x2h,
 // :121-151 for h2x).  Differences:
@@ -13,7 +13,8 @@
 //         value h: h2x values (one per head), sum_j alpha * e_w * v_ij * rel_x   -> o3  [N][16][3]
 //   * edge_fused_kernel runs both phases of an attention in one launch (image swap in LDS for x2h, both images
 //     resident for h2x) and, for h2x, the VN-linear + batch-norm statistics of the coordinate update in its epilogue.
-//     (Since round 2 the default kernels are those of sm_edge16.h; these are option edge_bf16 = 1, the exactly split form.)
+//     (Round 2 made the two-piece f16 kernels of sm_edge16.h the default, round 4 the streaming kernels of sm_edge_stream.h, which
+//     use this file's exact three-piece arithmetic; the phase kernels here remain as option edge_bf16 = 1.)
 // One job = the KP <= 16 neighbour slots of 16 / KP centre atoms = one 16-column tile, one job per wave where
 // the jobs fit; loads of a job are issued before the weight image is copied to LDS.
 #pragma once
