@@ -48,7 +48,7 @@ PROFILE_DIR = "r04"          # profiles/<dir>/pmc_traffic*.json hold the PMC tra
 CHAIN_STEPS = 1000                 # the metric is quoted for 1000-step chains
 # what the arithmetic is: fp32 inputs, outputs, accumulators and vector work; every matrix operand is split EXACTLY into three
 # bf16 pieces (8 + 8 + 8 = the 24 significand bits of fp32, exact for every value of magnitude >= 2^-110) and a product is the six piece products of
-# total order <= 2 with fp32 accumulation: the dropped terms are below 2^-24 |x w|.  This is the library's default mode and what
+# total order <= 2 with fp32 accumulation: each dropped term is below 2^-24 |x w| (mid x lo, lo x mid; lo x lo below 2^-32).  This is the library's default mode and what
 # `value` is measured on; `f16x2_mode` on the JSON line times the same chain with two-piece f16 operands (22-23 bits, three
 # products: the round-2/3 kernels), `f16_features_mode` with single f16 pieces (11 bits) -- optional modes, never `value`.
 DTYPE = "f32 (matrix operands split exactly into 3 x bf16 pieces = 24 bits, six piece products, fp32 accumulate)"

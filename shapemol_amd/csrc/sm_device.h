@@ -241,8 +241,9 @@ SM_DEV float u01_half(uint32_t x) { return (x >> 8) * (1.0f / 16777216.0f); }   
 // matrix cycles + vector cycles.  v_mfma_f32_16x16x32_bf16 is 16x faster per FLOP and does overlap.
 // A float is split EXACTLY into three bf16 pieces by truncation (8 + 8 + 8 significand bits):
 //     x = hi + mid + lo,   hi = x & 0xFFFF0000,  mid = (x - hi) & 0xFFFF0000,  lo = trunc_bf16(x - hi - mid)
-// and x*w is the sum of the six piece products of total order <= 2 (hh, hm, mh, hl, lh, mm); the dropped
-// ones are below 2^-24 |x w|.  Piece products are exact in fp32 and the MFMA accumulates in fp32.
+// and x*w is the sum of the six piece products of total order <= 2 (hh, hm, mh, hl, lh, mm); each dropped
+// one (ml, lm: below 2^-24 |x w|; ll: below 2^-32) is smaller than one ulp of the product.  Piece products are exact in fp32 and the
+// MFMA accumulates in fp32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 

@@ -6,7 +6,7 @@
 //
 // Arithmetic: every matrix operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits = the 24 of fp32, by
 // truncation, full fp32 exponent range: exact for every value of magnitude >= 2^-110, no scaling) and a product is the six piece products of total
-// order <= 2 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (sm_device.h); the dropped terms are below 2^-24 |x w|.
+// order <= 2 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (sm_device.h); each dropped term (mid x lo, lo x mid) is below 2^-24 |x w|.
 //
 // Structure (what is new): weights stationary in REGISTERS, activations streaming through LDS.
 //   * wave t2 < H / 16 is a CONSUMER: it holds row block t2 (16 output features = heads 2 t2, 2 t2 + 1) of the key and the
