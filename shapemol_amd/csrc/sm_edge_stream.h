@@ -52,8 +52,19 @@ struct EdgeStreamArgs {
 constexpr int kStreamProducers = 4, kStreamTPR = 2;      // producer waves; tiles per round
 #ifndef SM_STREAM_ABL
 #define SM_STREAM_ABL 0          // timing attribution builds only (bit 0: consumers skip their matrix products, 1: producers skip the
-#endif                           // first Linear's products, 2: producers skip LayerNorm, 3: producers skip the split, 4: no s_setprio for producers)
+#endif                           // first Linear's products, 2: producers skip LayerNorm, 3: producers skip the split, 4: no s_setprio for producers,
+                                 // 5: LayerNorm gain / shift not read from LDS, 6: first Linear's weight fragments not read from LDS, 7: every gather reads
+                                 // row 0, 8: consumers do not read the hidden fragments, 9: consumers skip softmax and sums, 11 / 12: no A[i] / B[j]
+                                 // gathers.  Ablations change the numbers a chain produces: compare per-kernel times, not step times)
 #define SM_SABL(bit) (((SM_STREAM_ABL) >> (bit)) & 1)
+// Attribution build (tools/kprof_stream.py): every wave accumulates where its time goes -- the work of its rounds, waiting for its
+// gathers, waiting at the round barriers -- and writes the sums once at its end (stamps[row of the wave][0..7], 100 MHz ticks).
+#ifdef SM_STREAM_PROF
+#define SM_PCLK(t) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#define SM_PROF(x) x
+#else
+#define SM_PROF(x)
+#endif
 
 // dynamic LDS map in 32-bit words
 template <int H, bool H2X>
@@ -126,8 +137,8 @@ SM_DEV void ln_relu_stream(float (&v)[NT * 4], const float *gamma, const float *
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float4 ga = ldg4(gamma + 16 * t + 4 * g);
-        const float4 be = ldg4(beta + 16 * t + 4 * g);
+        const float4 ga = SM_SABL(5) ? float4{1.f + g, 1.5f, 2.f + t, 0.5f} : ldg4(gamma + 16 * t + 4 * g);
+        const float4 be = SM_SABL(5) ? float4{0.1f, 0.2f + g, 0.3f, 0.4f + t} : ldg4(beta + 16 * t + 4 * g);
         v[4 * t + 0] = fmaxf((v[4 * t + 0] - mean) * rstd * ga.x + be.x, 0.f);
         v[4 * t + 1] = fmaxf((v[4 * t + 1] - mean) * rstd * ga.y + be.y, 0.f);
         v[4 * t + 2] = fmaxf((v[4 * t + 2] - mean) * rstd * ga.z + be.z, 0.f);
@@ -334,10 +345,13 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
             asm volatile("" : "+v"(opq));            //  here, not hoisted out of the round loop and spilled)
             qrow = qa < a.n_atoms ? ldg4(a.q + (size_t)GE::first_atom_of(tile) * H + 4 * (lane + opq)) : float4{0.f, 0.f, 0.f, 0.f};
         }
-        const float *pi = a.pre + (size_t)atom * a.ld_pre + 2 * H * MLP + 4 * g;
-        const float *pj = a.pre + (size_t)jn * a.ld_pre + 2 * H * MLP + H + 4 * g;
+        const float *pi = a.pre + (size_t)(SM_SABL(7) ? 0 : atom) * a.ld_pre + 2 * H * MLP + 4 * g;
+        const float *pj = a.pre + (size_t)(SM_SABL(7) ? 0 : jn) * a.ld_pre + 2 * H * MLP + H + 4 * g;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { ga[t] = ldg4(pi + 16 * t); gb[t] = ldg4(pj + 16 * t); }
+        for (int t = 0; t < NT; ++t) {
+            ga[t] = SM_SABL(11) ? float4{0.1f, 0.2f, 0.3f, 0.4f} : ldg4(pi + 16 * t);
+            gb[t] = SM_SABL(12) ? float4{0.1f, 0.2f, 0.3f, 0.4f} : ldg4(pj + 16 * t);
+        }
         if (!fold) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) { xi[k] = a.x[atom * 3 + k]; xj[k] = a.x[jn * 3 + k]; }
@@ -346,6 +360,8 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
     };
 
     SM_TICK(a.stamps, 0);
+    SM_PROF(unsigned long long p_t0; unsigned long long p_ta; unsigned long long p_tb; unsigned long long p_tc; unsigned long long p_cmp = 0; unsigned long long p_gw = 0;
+            unsigned long long p_bar = 0; unsigned long long p_pro = 0; unsigned long long p_first = 0; SM_PCLK(p_t0);)
     if (!SM_SABL(4)) __builtin_amdgcn_s_setprio(3);      // the producers are the critical path of a round: their instructions go first
     if (tile_of(0) < wg_end) {             // the first unit's rows: the oldest memory operations of the wave
         const int j0 = peek(tile_of(0));
@@ -398,7 +414,9 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
             const u32x4 *w1 = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned *>(part) + M::P_W1) + lane;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const u32x4 ah = w1[(0 * NT + t) * 64], am = w1[(1 * NT + t) * 64], al = w1[(2 * NT + t) * 64];
+                u32x4 ah, am, al;
+                if (!SM_SABL(6)) { ah = w1[(0 * NT + t) * 64]; am = w1[(1 * NT + t) * 64]; al = w1[(2 * NT + t) * 64]; }
+                else { ah = u32x4{0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u + t, 0x3f803f80u}; am = ah + 0x00010001u; al = am + 0x00010001u; }
                 f32x4 c = acc[t];
                 if (!SM_SABL(1)) {
                 c = mfma_bf16(al, rh, c);      // smallest terms first
@@ -467,13 +485,22 @@ SM_DEV void stream_producer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
         if (r == 1) SM_TICK(a.stamps, 7);
     };
 
+    SM_PROF(SM_PCLK(p_ta); p_pro = p_ta - p_t0;)
     produce(0);
+    SM_PROF(SM_PCLK(p_tb); p_first = p_tb - p_ta; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SM_PCLK(p_tc); p_gw += p_tc - p_tb;)
     __syncthreads();
+    SM_PROF(SM_PCLK(p_ta); p_bar += p_ta - p_tc;)
     SM_TICK(a.stamps, 2);
     for (int r = 0; r < rounds; ++r) {
         produce(r + 1);
+        SM_PROF(SM_PCLK(p_tb); p_cmp += p_tb - p_ta; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SM_PCLK(p_tc); p_gw += p_tc - p_tb;)
         __syncthreads();
+        SM_PROF(SM_PCLK(p_ta); p_bar += p_ta - p_tc;)
     }
+    SM_PROF(if (a.stamps != nullptr && lane == 0) {
+        unsigned long long *row = a.stamps + ((size_t)blockIdx.x * GE::NWAVE + G.wave) * 8;
+        row[0] = p_t0; row[1] = p_pro; row[2] = p_first; row[3] = p_cmp; row[4] = p_gw; row[5] = p_bar; row[6] = p_ta - p_t0; row[7] = (unsigned long long)rounds;
+    })
 }
 
 // ---- consumer wave t2 = G.wave ------------------------------------------------------------------------------------------------
@@ -485,8 +512,11 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
     const unsigned *ldsu = reinterpret_cast<const unsigned *>(lds);
     const int lane = G.lane, wave = G.wave, n = G.n, g = G.g, wg_first = G.wg_first, wg_end = G.wg_end, rounds = G.rounds;
     SM_TICK(a.stamps, 0);
+    SM_PROF(unsigned long long p_t0; unsigned long long p_ta; unsigned long long p_tb; unsigned long long p_cmp = 0; unsigned long long p_bar = 0; unsigned long long p_pro = 0;
+            unsigned long long p_first = 0; SM_PCLK(p_t0);)
     int span0, span_n;
     stream_prologue<H, KP, H2X>(a, G, lds, span0, span_n);
+    SM_PROF(SM_PCLK(p_ta); p_pro = p_ta - p_t0;)
     SM_TICK(a.stamps, 1);
     // this wave's row block of the second Linears, in registers for the whole launch (loaded while the producers work on the
     // first round)
@@ -507,7 +537,9 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
             b2v = ldg4(a.b2v + 16 * wave + 4 * g);
         }
     }
+    SM_PROF(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SM_PCLK(p_tb); p_first = p_tb - p_ta;)
     __syncthreads();
+    SM_PROF(SM_PCLK(p_ta); p_bar += p_ta - p_tb;)
     SM_TICK(a.stamps, 2);
     for (int r = 0; r < rounds; ++r) {
 #pragma unroll
@@ -519,7 +551,8 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
             f32x4 ksm = {0.f, 0.f, 0.f, 0.f}, kbg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int b = 0; b < NB; ++b)
-                kbg = mfma_bf16x6(wk[0][b], wk[1][b], wk[2][b], hk[(0 * NB + b) * 64], hk[(1 * NB + b) * 64], hk[(2 * NB + b) * 64], ksm, kbg);
+                kbg = SM_SABL(8) ? mfma_bf16x6(wk[0][b], wk[1][b], wk[2][b], wk[0][b], wk[1][b], wk[2][b], ksm, kbg)
+                                 : mfma_bf16x6(wk[0][b], wk[1][b], wk[2][b], hk[(0 * NB + b) * 64], hk[(1 * NB + b) * 64], hk[(2 * NB + b) * 64], ksm, kbg);
             const int atom_raw = GE::atom_of(tile, n);
             const bool atom_ok = atom_raw < a.n_atoms;
             const int orow = GE::HALF ? tile : atom_raw;           // k > 16: every half-atom tile stores its own (tile-normalised) rows
@@ -529,12 +562,15 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
             // The bias of the key MLP's second Linear adds the same q_i . b2 to every neighbour's logit and cancels in the softmax.
             const float4 qv = *reinterpret_cast<const float4 *>(lds + M::O_Q + slot * M::Q_TILE + (n / SEGW) * H + 16 * wave + 4 * g);
             float pp = qv.x * (kbg[0] + ksm[0]) + qv.y * (kbg[1] + ksm[1]) + qv.z * (kbg[2] + ksm[2]) + qv.w * (kbg[3] + ksm[3]);
-            pp = sum_xor16(pp);
-            pp = okc ? pp * 0.35355339059327373f : -INFINITY;
-            const float mx = seg_max<SEGW>(pp);
-            const float e = okc ? fast_exp(pp - mx) : 0.f;
-            const float ssum = seg_sum<SEGW>(e);
-            const float alpha = ssum > 0.f ? e * __builtin_amdgcn_rcpf(ssum) : 0.f;
+            float mx = 0.f, ssum = 1.f, alpha = pp;
+            if (!SM_SABL(9)) {
+                pp = sum_xor16(pp);
+                pp = okc ? pp * 0.35355339059327373f : -INFINITY;
+                mx = seg_max<SEGW>(pp);
+                const float e = okc ? fast_exp(pp - mx) : 0.f;
+                ssum = seg_sum<SEGW>(e);
+                alpha = ssum > 0.f ? e * __builtin_amdgcn_rcpf(ssum) : 0.f;
+            }
             const bool store = atom_ok && (n % SEGW) == 0;
             if constexpr (GE::HALF) {        // this tile's softmax state of head 2 wave + (g >> 1), for the combine (online-softmax identity)
                 if (store && (g & 1) == 0)
@@ -545,13 +581,14 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
                 f32x4 vsm = {0.f, 0.f, 0.f, 0.f}, vbg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    vbg = mfma_bf16x6(wv[0][b], wv[1][b], wv[2][b], hv[(0 * NB + b) * 64], hv[(1 * NB + b) * 64], hv[(2 * NB + b) * 64], vsm, vbg);
+                    vbg = SM_SABL(8) ? mfma_bf16x6(wv[0][b], wv[1][b], wv[2][b], wv[0][b], wv[1][b], wv[2][b], vsm, vbg)
+                                     : mfma_bf16x6(wv[0][b], wv[1][b], wv[2][b], hv[(0 * NB + b) * 64], hv[(1 * NB + b) * 64], hv[(2 * NB + b) * 64], vsm, vbg);
                 // sum_j a_ij (W2 hid_ij + b2) = sum_j a_ij W2 hid_ij + b2 sum_j a_ij
                 const float aw = okc ? alpha * wc : 0.f;
-                const float sw = seg_sum<SEGW>(aw);
+                const float sw = SM_SABL(9) ? aw : seg_sum<SEGW>(aw);
                 float o[4];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) o[rr] = seg_sum<SEGW>(aw * (vbg[rr] + vsm[rr]));
+                for (int rr = 0; rr < 4; ++rr) o[rr] = SM_SABL(9) ? aw * (vbg[rr] + vsm[rr]) : seg_sum<SEGW>(aw * (vbg[rr] + vsm[rr]));
                 if (store) stg4(a.out + (size_t)orow * H + 16 * wave + 4 * g,
                                 float4{o[0] + sw * b2v.x, o[1] + sw * b2v.y, o[2] + sw * b2v.z, o[3] + sw * b2v.w});
             } else {
@@ -560,7 +597,7 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
                 const float av = alpha * vt[head * 16 + n];          // (value + bias) x edge weight, 0 where there is no edge
                 float o[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) o[k] = seg_sum<SEGW>(av * vt[256 + 16 * k + n]);
+                for (int k = 0; k < 3; ++k) o[k] = SM_SABL(9) ? av * vt[256 + 16 * k + n] : seg_sum<SEGW>(av * vt[256 + 16 * k + n]);
                 if (store && (g & 1) == 0) {
                     float *op = a.out + (size_t)orow * 48 + stream_row_of_head<NT>(head) * 3;
                     op[0] = o[0]; op[1] = o[1]; op[2] = o[2];
@@ -570,9 +607,15 @@ SM_DEV void stream_consumer(const EdgeStreamArgs &a, const StreamGeo<H, KP, H2X>
         if (r == 0) SM_TICK(a.stamps, 3);      // (diagnostic build: this wave's work of rounds 0, 1, 2 done; 6: last barrier passed)
         if (r == 1) SM_TICK(a.stamps, 4);
         if (r == 2) SM_TICK(a.stamps, 5);
+        SM_PROF(SM_PCLK(p_tb); p_cmp += p_tb - p_ta;)
         __syncthreads();
+        SM_PROF(SM_PCLK(p_ta); p_bar += p_ta - p_tb;)
     }
     SM_TICK(a.stamps, 6);
+    SM_PROF(if (a.stamps != nullptr && lane == 0) {
+        unsigned long long *row = a.stamps + ((size_t)blockIdx.x * GE::NWAVE + wave) * 8;
+        row[0] = p_t0; row[1] = p_pro; row[2] = p_first; row[3] = p_cmp; row[4] = 0; row[5] = p_bar; row[6] = p_ta - p_t0; row[7] = (unsigned long long)rounds;
+    })
 }
 
 // One workgroup barrier per round; every role runs its own copy of the prologue, the loop and the barriers (a barrier counts

@@ -598,24 +598,35 @@ node_chain6_kernel(NodeChainArgs a) {
 
     SM_TICK(a.stamps, 0);
     // ---- stage 0: weights of the output MLP; [att | h] tiles -> fragments ----------------------------
+    // The activation rows are requested BEFORE the weights: vector memory operations complete in order, and behind the 48 weight
+    // loads of a wave the staging pass waits for them too (18.96 -> 18.61 us per launch at B = 256).
     u32x4 w1[3][2 * NB], w2[3][NB];
-    load_w(a.w1img6, w1);
-    for (int idx = threadIdx.x; idx < CC * 2 * NB * 64; idx += NT * 64) {
+    constexpr int SITER = CC * 2 * NB * 64 / (NT * 64);
+    float4 sv0[SITER], sv1[SITER];
+#pragma unroll
+    for (int it = 0; it < SITER; ++it) {
+        const int idx = threadIdx.x + it * NT * 64;
         const int sl = idx & 63, sb = (idx >> 6) % (2 * NB), sc = idx / (64 * 2 * NB);
         const int at = min((ct0 + sc) * 16 + (sl & 15), a.n_atoms - 1);
         const float *src = (sb < NB ? a.att + (size_t)at * H + 32 * sb : a.h + (size_t)at * H + 32 * (sb - NB)) + 4 * (sl >> 4);
-        const float4 v0 = ldg4(src), v1 = ldg4(src + 16);
-        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        sv0[it] = ldg4(src); sv1[it] = ldg4(src + 16);
+    }
+    float4 hres[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) hres[c] = ldg4(a.h + (size_t)atom_of(c) * H + f0);    // residual
+    const float4 b1 = ldg4(a.b1 + f0), b2 = ldg4(a.b2 + f0);
+    load_w(a.w1img6, w1);
+#pragma unroll
+    for (int it = 0; it < SITER; ++it) {
+        const int idx = threadIdx.x + it * NT * 64;
+        const int sl = idx & 63, sb = (idx >> 6) % (2 * NB), sc = idx / (64 * 2 * NB);
+        const float v[8] = {sv0[it].x, sv0[it].y, sv0[it].z, sv0[it].w, sv1[it].x, sv1[it].y, sv1[it].z, sv1[it].w};
         u32x4 hi, mid, lo;
         split3_bf16(v, hi, mid, lo);
         u32x4 *dst = fin + (sb * CC + sc) * 64 + frag_slot(sb, sl);
         dst[0] = hi; dst[2 * NB * CC * 64] = mid; dst[2 * 2 * NB * CC * 64] = lo;
     }
     load_w(a.w2img6, w2);
-    float4 hres[CC];
-#pragma unroll
-    for (int c = 0; c < CC; ++c) hres[c] = ldg4(a.h + (size_t)atom_of(c) * H + f0);    // residual
-    const float4 b1 = ldg4(a.b1 + f0), b2 = ldg4(a.b2 + f0);
     __syncthreads();
     SM_TICK(a.stamps, 1);
 
