@@ -453,6 +453,38 @@ def test_chain_b256_s1000_golden(mode):
     assert errs["pos_end_median_mol"] < 5e-4, errs           # the bulk of the molecules stays on the reference's trajectory
 
 
+def _pinned_free_run(name, mode, c, tail, pins):
+    """One free-running graph-replayed chain of fixture `c` (the reference's noise) with the kNN pins applied; errors per molecule at
+    every recorded state (the every-50th snapshots of `c`, then `tail` = (first step, spacing, positions, types))."""
+    from util import record
+    m = hip(mode)
+    B, S, seed, every = int(c["B"]), int(c["S"]), int(c["seed"]), int(c["every"])
+    bb = synth.synthetic_batch(B, seed=seed, max_atoms=38)
+    assert np.array_equal(bb["counts"], c["counts"])
+    eps, u = hash_noise(len(bb["batch"]), S, seed)
+    m.set_knn_pins(pins["step"], pins["atom"], pins["nbr"])
+    try:
+        r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u, use_graph=True)
+    finally:
+        m.set_knn_pins()
+    pos_traj, v_traj = torch.stack(r["pos_traj"]).numpy(), torch.stack(r["v_traj"]).numpy()
+    off = np.concatenate([[0], np.cumsum(bb["counts"])])
+    mol = lambda p, q: np.maximum.reduceat(np.abs(p.astype(np.float64) - q).max(-1), off[:-1])  # noqa: E731
+    f0, ev = tail[0], tail[1]
+    states = [(j * every, c["pos_traj_sub"][j], c["v_traj_sub"][j]) for j in range(len(c["pos_traj_sub"]))]
+    states += [(f0 + i * ev, tail[2][i], tail[3][i]) for i in range(len(tail[2]))]
+    per_state = {int(st): float(mol(pos_traj[st], p).max()) for st, p, _ in states}
+    over = {int(st): int((mol(pos_traj[st], p) > POS_TOL).sum()) for st, p, _ in states}
+    v_bad = int(sum((v_traj[st] != np.asarray(v).astype(np.int64)).sum() for st, _, v in states) + (r["v"].cpu().numpy() != c["v"]).sum())
+    end = mol(r["pos"].cpu().numpy(), c["pos"])
+    rec = dict(mode=mode, pins=int(len(pins["step"])), atom_type_mismatches=v_bad, worst_through_980=max(v for k, v in per_state.items() if k <= 980),
+               at_990=per_state.get(990), end_max=float(end.max()), end_median=float(np.median(end)), end_mols_over_1e_4=int((end > POS_TOL).sum()),
+               mols_over_1e_4_worst_state=max(over.values()),
+               per_state={str(k): v for k, v in per_state.items() if k % 100 == 0 or k > 940})
+    record(name, **rec)
+    return rec
+
+
 def test_chain_b256_s1000_free_run_pinned_golden(mode):
     """The literal north-star gate, as far as float32 allows: BASELINE configs[1], 256 molecules x 1000 reverse steps FREE-RUNNING
     from the initial state (one call, graph replay, the reference's noise) against the reference's own run -- with the kNN choice
@@ -471,34 +503,28 @@ def test_chain_b256_s1000_free_run_pinned_golden(mode):
         at 1.9e-4 with two molecules beyond 1e-4; the kernels measure 4.6e-5 / 5.6e-5 / 1.4e-4 .. 2.7e-4 (six or seven
         molecules; the end value moves by that much when a summation order inside one kernel changes).  The last window is
         held to 1e-4 from the reference's own state by test_chain_b256_s1000_windows_golden."""
-    from util import record
-    m = hip(mode)
-    c, ct, pins = golden("chain_b256_s1000_hash.npz"), golden("chain_b256_s1000_tail_hash.npz"), golden("chain_b256_s1000_pins.npz")
-    B, S, seed, every = int(c["B"]), int(c["S"]), int(c["seed"]), int(c["every"])
-    bb = synth.synthetic_batch(B, seed=seed, max_atoms=38)
-    assert np.array_equal(bb["counts"], c["counts"])
-    eps, u = hash_noise(len(bb["batch"]), S, seed)
-    m.set_knn_pins(pins["step"], pins["atom"], pins["nbr"])
-    try:
-        r = _chain(m, bb["init_pos"], bb["init_v"], bb["batch"], bb["shape"], S, eps, u, use_graph=True)
-    finally:
-        m.set_knn_pins()
-    pos_traj, v_traj = torch.stack(r["pos_traj"]).numpy(), torch.stack(r["v_traj"]).numpy()
-    off = np.concatenate([[0], np.cumsum(bb["counts"])])
-    mol = lambda p, q: np.array([np.abs(p.astype(np.float64) - q).max(-1)[off[b]:off[b + 1]].max() for b in range(B)])  # noqa: E731
-    f0, ev = int(ct["first_step"]), int(ct["every"])
-    states = [(j * every, c["pos_traj_sub"][j], c["v_traj_sub"][j]) for j in range(len(c["pos_traj_sub"]))]
-    states += [(f0 + i * ev, ct["pos_traj_tail"][i], ct["v_traj_tail"][i]) for i in range(len(ct["pos_traj_tail"]))]
-    per_state = {int(st): float(mol(pos_traj[st], p).max()) for st, p, _ in states}
-    v_bad = int(sum((v_traj[st] != np.asarray(v).astype(np.int64)).sum() for st, _, v in states) + (r["v"].cpu().numpy() != c["v"]).sum())
-    end = mol(r["pos"].cpu().numpy(), c["pos"])
-    rec = dict(mode=mode, pins=int(len(pins["step"])), atom_type_mismatches=v_bad, worst_through_980=max(v for k, v in per_state.items() if k <= 980),
-               at_990=per_state.get(990), end_max=float(end.max()), end_median=float(np.median(end)), end_mols_over_1e_4=int((end > POS_TOL).sum()),
-               per_state={str(k): v for k, v in per_state.items() if k % 100 == 0 or k > 940})
-    record("chain_b256_s1000_free_run_pinned_golden", **rec)
-    assert v_bad == 0, rec
+    c, ct = golden("chain_b256_s1000_hash.npz"), golden("chain_b256_s1000_tail_hash.npz")
+    rec = _pinned_free_run("chain_b256_s1000_free_run_pinned_golden", mode, c, (int(ct["first_step"]), int(ct["every"]), ct["pos_traj_tail"], ct["v_traj_tail"]),
+                           golden("chain_b256_s1000_pins.npz"))
+    assert rec["atom_type_mismatches"] == 0, rec
     assert rec["worst_through_980"] < POS_TOL, rec
     assert rec["at_990"] < 1.5e-4 and rec["end_max"] < 5e-4 and rec["end_mols_over_1e_4"] <= 10, rec
+
+
+def test_chain_b1024_s1000_free_run_pinned_golden(mode):
+    """The same gate at BASELINE configs[2]'s batch size (the per-GPU share of configs[3]): 1024 molecules x 1000 reverse steps
+    free-running with the reference's fragile kNN choices pinned (tests/golden/chain_b1024_s1000_pins.npz, recorded by re-running
+    the reference, which reproduced the committed chain bit for bit).  Four times the molecules of the B = 256 gate, hence four
+    times the draws from the same tail of rounding-difference growth: the bounds are the B = 256 ones with the molecule counts
+    scaled."""
+    if not os.path.exists(os.path.join(GOLDEN, "chain_b1024_s1000_pins.npz")):
+        pytest.skip("fixture chain_b1024_s1000_pins.npz not generated (tests/golden/make_golden_r2.py b1024_pins, ~2.5 CPU-hours)")
+    c = golden("chain_b1024_s1000_hash.npz")
+    rec = _pinned_free_run("chain_b1024_s1000_free_run_pinned_golden", mode, c, (int(c["tail_first"]), int(c["tail_every"]), c["pos_traj_tail"], c["v_traj_tail"]),
+                           golden("chain_b1024_s1000_pins.npz"))
+    assert rec["atom_type_mismatches"] == 0, rec
+    assert rec["worst_through_980"] < POS_TOL, rec
+    assert rec["at_990"] < 1.5e-4 and rec["end_max"] < 5e-4 and rec["end_mols_over_1e_4"] <= 40, rec
 
 
 def test_chain_b1024_s50_golden(mode):

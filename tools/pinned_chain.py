@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool: the free-running B = 256 x 1000 chain with the reference's fragile kNN choices pinned, error per snapshot.
-    python tools/pinned_chain.py [--mode exact|f16x2] [--thr 5e-4] [--pins tests/golden/chain_b256_s1000_pins.npz]"""
+"""Developer tool: the free-running B = 256 (or 1024) x 1000 chain with the reference's fragile kNN choices pinned, error per snapshot.
+    python tools/pinned_chain.py [--case b256|b1024] [--mode exact|f16x2] [--thr 5e-4] [--pins tests/golden/chain_b256_s1000_pins.npz]"""
 import argparse
 import os
 import sys
@@ -17,10 +17,16 @@ DEV = "cuda:0"
 ap = argparse.ArgumentParser()
 ap.add_argument("--mode", default="exact")
 ap.add_argument("--thr", type=float, default=1.0)
-ap.add_argument("--pins", default=os.path.join(ROOT, "tests/golden/chain_b256_s1000_pins.npz"))
+ap.add_argument("--pins", default="")
+ap.add_argument("--case", default="b256", choices=["b256", "b1024"])
 a = ap.parse_args()
-c, ct = golden("chain_b256_s1000_hash.npz"), golden("chain_b256_s1000_tail_hash.npz")
-pins = np.load(a.pins)
+c = golden(f"chain_{a.case}_s1000_hash.npz")
+if a.case == "b256":
+    ct = golden("chain_b256_s1000_tail_hash.npz")
+    tail = (int(ct["first_step"]), int(ct["every"]), ct["pos_traj_tail"])
+else:
+    tail = (int(c["tail_first"]), int(c["tail_every"]), c["pos_traj_tail"])
+pins = np.load(a.pins or os.path.join(ROOT, f"tests/golden/chain_{a.case}_s1000_pins.npz"))
 m = hip_model()
 if a.mode == "exact":
     m.set_option("edge_bf16", 2); m.set_option("node_f16", 0)
@@ -46,10 +52,10 @@ def mol_err(p, q):
 for i, st in enumerate(range(0, S, every)):
     me = mol_err(pos[st], c["pos_traj_sub"][i])
     print(f"  step {st:4d}: max {me.max():.2e} median {np.median(me):.2e} mols>1e-4 {int((me > 1e-4).sum())} v-mismatch {int((vt[st] != c['v_traj_sub'][i]).sum())}")
-f0, ev = int(ct["first_step"]), int(ct["every"])
-for i in range(len(ct["pos_traj_tail"])):
+f0, ev = tail[0], tail[1]
+for i in range(len(tail[2])):
     st = f0 + i * ev
-    me = mol_err(pos[st], ct["pos_traj_tail"][i])
+    me = mol_err(pos[st], tail[2][i])
     print(f"  step {st:4d}: max {me.max():.2e} median {np.median(me):.2e} mols>1e-4 {int((me > 1e-4).sum())} worst mol {int(me.argmax())}")
 me = mol_err(r["pos"].cpu().numpy(), c["pos"])
 print(f"  end      : max {me.max():.2e} median {np.median(me):.2e} mols>1e-4 {int((me > 1e-4).sum())} worst mols {np.argsort(-me)[:8].tolist()} {np.sort(me)[::-1][:8]}")
