@@ -5,7 +5,7 @@ choice pinned to the reference's at the same (step, atom) pairs the GPU test pin
 the only discontinuity of the path removed, what is left is the growth of float32 rounding differences along the chain -- the
 floor any float32 implementation of this chain sits on.  CPU only, ~15-25 minutes.
 
-    python tools/oracle_pinned.py [--threads 6] [--thr 5e-4] -> profiles/r04/oracle_pinned_b256.json
+    python tools/oracle_pinned.py [--case b256|b1024] [--threads 6] [--thr 5e-4] -> profiles/r04/oracle_pinned_<case>.json
 """
 import argparse
 import json
@@ -27,11 +27,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--thr", type=float, default=1.0)
-    ap.add_argument("--pins", default=os.path.join(ROOT, "tests", "golden", "chain_b256_s1000_pins.npz"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04", "oracle_pinned_b256.json"))
+    ap.add_argument("--case", default="b256", choices=["b256", "b1024"], help="b1024: ~1.5 CPU-hours")
+    ap.add_argument("--pins", default="")
+    ap.add_argument("--out", default="")
     a = ap.parse_args()
+    a.pins = a.pins or os.path.join(ROOT, "tests", "golden", f"chain_{a.case}_s1000_pins.npz")
+    a.out = a.out or os.path.join(ROOT, "profiles", "r04", f"oracle_pinned_{a.case}.json")
     torch.set_num_threads(a.threads)
-    c, ct = golden("chain_b256_s1000_hash.npz"), golden("chain_b256_s1000_tail_hash.npz")
+    c = golden(f"chain_{a.case}_s1000_hash.npz")
+    if a.case == "b256":
+        ct = golden("chain_b256_s1000_tail_hash.npz")
+        tail = (int(ct["first_step"]), int(ct["every"]), ct["pos_traj_tail"])
+    else:
+        tail = (int(c["tail_first"]), int(c["tail_every"]), c["pos_traj_tail"])
     pins = np.load(a.pins)
     keep = pins["margin"] < a.thr
     p_step, p_atom, p_nbr = pins["step"][keep].astype(np.int64), pins["atom"][keep].astype(np.int64), pins["nbr"][keep].astype(np.int64)
@@ -78,9 +86,9 @@ def main():
         e = mol(np.abs(pos_traj[j * every].astype(np.float64) - c["pos_traj_sub"][j]).max(-1))
         out["per_snapshot"].append({"step": j * every, "max": float(e.max()), "median": float(np.median(e)), "n_over_1e-4": int((e > 1e-4).sum()),
                                     "atom_type_mismatches": int((v_traj[j * every] != c["v_traj_sub"][j]).sum())})
-    f0, ev = int(ct["first_step"]), int(ct["every"])
-    for i in range(len(ct["pos_traj_tail"])):
-        e = mol(np.abs(pos_traj[f0 + i * ev].astype(np.float64) - ct["pos_traj_tail"][i]).max(-1))
+    f0, ev = tail[0], tail[1]
+    for i in range(len(tail[2])):
+        e = mol(np.abs(pos_traj[f0 + i * ev].astype(np.float64) - tail[2][i]).max(-1))
         out["per_snapshot"].append({"step": f0 + i * ev, "max": float(e.max()), "median": float(np.median(e)), "n_over_1e-4": int((e > 1e-4).sum())})
     e = mol(np.abs(r["pos"].numpy().astype(np.float64) - c["pos"]).max(-1))
     out["end"] = {"step": S - 1, "max": float(e.max()), "median": float(np.median(e)), "n_over_1e-4": int((e > 1e-4).sum()),

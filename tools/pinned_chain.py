@@ -30,6 +30,8 @@ pins = np.load(a.pins or os.path.join(ROOT, f"tests/golden/chain_{a.case}_s1000_
 m = hip_model()
 if a.mode == "exact":
     m.set_option("edge_bf16", 2); m.set_option("node_f16", 0)
+else:
+    m.set_option("node_f16", 1); m.set_option("edge_bf16", 3)
 B, S, seed, every = int(c["B"]), int(c["S"]), int(c["seed"]), int(c["every"])
 bb = synth.synthetic_batch(B, seed=seed, max_atoms=38)
 eps, u = hash_noise(len(bb["batch"]), S, seed)
