@@ -523,8 +523,9 @@ def test_chain_b1024_s1000_free_run_pinned_golden(mode):
       * every molecule within 1e-4 at every recorded state through reverse step 950 (measured 5.7e-5 exact / 8.4e-5 two-piece);
       * steps 960-990: at most 8 molecules beyond 1e-4 at any state, none beyond 5e-4 (measured 4 / 5 molecules, 2.5e-4 / 2.8e-4);
       * end state: median below 5e-5 (1.3e-5 / 1.8e-5), at most 64 of the 1024 molecules beyond 1e-4 (26 / 32), none beyond 1e-2
-        (2.3e-3 / 2.5e-3: molecule 435 in both modes).  The CPU oracle under the same pins is the measure of the float32 floor at
-        this size too: tools/oracle_pinned.py --case b1024 -> profiles/r04/oracle_pinned_b1024.json."""
+        (2.3e-3 / 2.5e-3: molecule 435 in both modes).  The float32 floor at this size, measured with the CPU oracle under the same
+        pins (tools/oracle_pinned.py --case b1024 -> profiles/r04/oracle_pinned_b1024.json): 4.9e-5 after step 950, 1.6e-4 after 990,
+        1.5e-3 at the end with 18 molecules beyond 1e-4 -- and its worst molecule is 435 too."""
     from util import GOLDEN
     if not os.path.exists(os.path.join(GOLDEN, "chain_b1024_s1000_pins.npz")):
         pytest.skip("fixture chain_b1024_s1000_pins.npz not generated (tests/golden/make_golden_r2.py b1024_pins, ~2.5 CPU-hours)")
