@@ -280,6 +280,8 @@ int shapemol_seg_attention_backward(const float *d_q, const float *d_k, const fl
  *          "edge_waves" (waves per workgroup of the edge kernels, 1..12; 0 = automatic: ceil(jobs / CUs) [default]; a
  *                        value other than 0 also selects the separate launches),
  *          "lin_waves"  (1..16 waves per workgroup of node_linear_kernel, tuning),
+ *          "stream_whole_rounds" (streaming edge kernels, k <= 16: 1 = tiles per workgroup rounded up to whole rounds of two; 0 =
+ *                        ceil(tiles / CUs), the last round of an odd count has one tile [default]; tuning, same results),
  *          "stamps", "kstamp_sel" (clock-stamp diagnostics; only meaningful in the --stamps build).
  * Changing an option invalidates a captured graph (the next _sample re-captures). */
 int shapemol_set_option(shapemol_ctx *ctx, const char *name, int64_t value);

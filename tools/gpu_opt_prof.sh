@@ -6,7 +6,7 @@ i=0
 for o in "$@"; do
   i=$((i+1)); args=""; for kv in $o; do args="$args --opt $kv"; done
   rm -rf gpurun_out/optp_$i
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/optp_$i -- python3 bench.py --steps 100 --warmup 20 --cpu-steps 0 --concurrent 0 --exact-steps 0 --profile-steps 0 $args > gpurun_out/optp_$i.log 2>&1 || { echo "$o FAILED" >> gpurun_out/optp.txt; continue; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/optp_$i -- python3 bench.py --batch ${BATCH:-256} --steps 100 --warmup 20 --cpu-steps 0 --concurrent 0 --exact-steps 0 --profile-steps 0 $args > gpurun_out/optp_$i.log 2>&1 || { echo "$o FAILED" >> gpurun_out/optp.txt; continue; }
   python - "$o" $i >> gpurun_out/optp.txt <<'PY'
 import csv,glob,sys
 f=glob.glob(f"gpurun_out/optp_{sys.argv[2]}/**/*kernel_stats.csv",recursive=True)[0]
