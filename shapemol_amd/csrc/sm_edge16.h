@@ -2,8 +2,10 @@
 // default of rounds 2-3, since round 4 the optional faster mode -- the default is the exactly split form of sm_edge_stream.h).  Same semantics and formulation as sm_edge_bf16.h (reference: models/uni_transformer.py:48-81 for x2h,
 // :121-151 for h2x); what changes is the arithmetic of the matrix products and, through it, the kernel's structure:
 //
-//   * a float is carried as hi + lo with hi = f16(x), lo = f16(x - hi), both round-to-nearest: 22 significand bits
-//     (|x - hi - lo| <= 2^-22 |x|, typically 2^-23), and x * w = hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with
+//   * a float is carried as hi + lo with hi = f16(x), lo = f16(x - hi), both round-to-nearest: 22 significand bits ONLY where
+//     the low piece is a normal fp16 number -- |x - hi - lo| <= 2^-22 |x| for |x| >= 2^-3, an ABSOLUTE 2^-25 below (the residual
+//     of a smaller x is an fp16 subnormal: weights below 1/8, most of them, carry 19-21 bits; round 3's "22 bits" overstated
+//     the mode, which is why it is no longer the default) --, and x * w = hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with
 //     fp32 accumulation (the dropped lo*lo term is < 2^-22 |x w|).  That is three matrix instructions per product where
 //     the exactly split bf16 pieces (8 + 8 + 8 bits) need six, at an error per term that stays below the rounding of
 //     the fp32 accumulation of a 128-term sum.  fp16 subnormal pieces are honoured by the matrix cores
