@@ -259,3 +259,42 @@ def test_diffusion_loss_gradients_oracle_golden():
     total = np.sqrt(sum(float((gr.astype(np.float64) ** 2).sum()) for gr in grads.values() if gr is not None))
     assert abs(total - float(g["total_grad_norm"])) < 1e-4 * float(g["total_grad_norm"]), (total, float(g["total_grad_norm"]))
     assert worst < 1e-4
+
+
+@pytest.mark.parametrize("case", ["b256", "b1024"])
+def test_knn_pin_fixtures_against_the_reference_snapshots(case):
+    """The pins of the free-running gates (tests/golden/chain_<case>_s1000_pins.npz: the reference's neighbour lists where its k-th
+    and (k+1)-th candidates are closer than a relative 5e-4 in squared distance) checked against the reference's own recorded
+    states: well-formed (sorted by step, neighbours inside the atom's molecule, distinct, no self), and at every (step, atom)
+    whose preceding state is a snapshot of the chain fixture the pinned list is a set of k nearest atoms up to the recorded
+    margin -- i.e. the pins only ever choose between candidates a float32 implementation cannot tell apart."""
+    import os
+    from util import GOLDEN, golden, synth
+    if not os.path.exists(os.path.join(GOLDEN, f"chain_{case}_s1000_pins.npz")):
+        pytest.skip("pins fixture not generated")
+    c, p = golden(f"chain_{case}_s1000_hash.npz"), golden(f"chain_{case}_s1000_pins.npz")
+    assert bool(p["reproduces_committed_chain"])
+    step, atom, nbr, margin, thr = p["step"].astype(np.int64), p["atom"].astype(np.int64), p["nbr"].astype(np.int64), p["margin"], float(p["thr"])
+    B, S, every = int(c["B"]), int(c["S"]), int(c["every"])
+    bb = synth.synthetic_batch(B, seed=int(c["seed"]), max_atoms=38)
+    batch, n, k = bb["batch"], len(bb["batch"]), nbr.shape[1]
+    assert np.all(np.diff(step) >= 0) and step.min() >= 0 and step.max() < S
+    assert atom.min() >= 0 and atom.max() < n and nbr.min() >= 0 and nbr.max() < n
+    assert np.all(batch[nbr] == batch[atom][:, None]) and np.all(nbr != atom[:, None])
+    assert np.all(np.sort(nbr, 1)[:, 1:] != np.sort(nbr, 1)[:, :-1])
+    assert np.all(margin < thr) and np.all(margin >= 0)
+    off = np.concatenate([[0], np.cumsum(bb["counts"])])
+    checked = 0
+    for j in range(len(c["pos_traj_sub"])):           # state after reverse step j * every = the state the graph of step j * every + 1 is built from
+        s = j * every + 1
+        lo, hi = np.searchsorted(step, s), np.searchsorted(step, s + 1)
+        x = c["pos_traj_sub"][j].astype(np.float64)
+        for e in range(lo, hi):
+            i, b = atom[e], batch[atom[e]]
+            cand = np.arange(off[b], off[b + 1])
+            cand = cand[cand != i]
+            d2 = ((x[cand] - x[i]) ** 2).sum(-1)
+            kth = np.sort(d2)[k - 1]
+            assert np.all(((x[nbr[e]] - x[i]) ** 2).sum(-1) <= kth * (1 + 4 * thr)), (case, s, i)
+            checked += 1
+    assert checked > 100, checked
